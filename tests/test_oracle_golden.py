@@ -1,0 +1,156 @@
+"""Pins the CPU oracle (oracle/bnn_oracle.c) against fixtures produced by the real
+reference (tests/golden/make_golden.py).  CPU only.
+
+Tolerance: atol = rtol = 1e-5, the reference suite's own bar
+(/root/reference/tests/test_nn/test_dense.py:11-12), fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import allclose, allclose_scaled, load_golden
+from oracle import oracle as orc
+import seeded
+
+LINEAR = ["linear_4x3", "linear_7x11", "linear_7x11_nobias", "linear_64x48", "linear_1x1"]
+CONV = ["conv_1_1_k1", "conv_3_4_k3_p1", "conv_4_6_k3_s2_d2_g2", "conv_mnist_pretrained"]
+
+
+def test_philox_published_kat():
+    # Random123 kat_vectors, philox4x32-10
+    assert [hex(v) for v in orc.philox4x32_10([0, 0, 0, 0], [0, 0])] == \
+        ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    assert [hex(v) for v in orc.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2)] == \
+        ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    assert [hex(v) for v in orc.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                                              [0xa4093822, 0x299f31d0])] == \
+        ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def test_eps_stream_is_standard_normal():
+    e = orc.eps_fill(0xC0FFEE, 3, 5, 7, 0, (1 << 20,))
+    assert abs(e.mean()) < 5e-3 and abs(e.std() - 1) < 5e-3
+    assert abs((e ** 3).mean()) < 2e-2 and abs((e ** 4).mean() - 3) < 5e-2
+    assert np.isfinite(e).all()
+    # streams / samples / epochs are distinct, and prefixes are stable
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 3, 6, 7, 0, (64,)))
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 4, 5, 7, 0, (64,)))
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 3, 5, 8, 0, (64,)))
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 3, 5, 7, 1, (64,)))
+    assert np.array_equal(e[:61], orc.eps_fill(0xC0FFEE, 3, 5, 7, 0, (61,)))
+
+
+def test_weightnormal_sigma_sample_kl():
+    g = load_golden("weightnormal_5x6x7")
+    assert allclose(orc.sigma(g["rho"]), g["sigma"])
+    # relative check too: sigma spans 1e-10 .. 50
+    assert np.allclose(orc.sigma(g["rho"]), g["sigma"], rtol=1e-5, atol=0)
+    assert allclose(orc.sample_affine(g["mu"], g["rho"], g["eps"]), g["w"])
+    kl = orc.kl_sum(g["mu"], g["rho"], float(g["prior_mu"]), float(g["prior_sigma"])) / g["mu"].size
+    assert abs(kl - float(g["kl_mean"])) <= 1e-5 * abs(float(g["kl_mean"]))
+
+
+@pytest.mark.parametrize("name", LINEAR + ["linear_mnist_pretrained"])
+def test_linear_forward(name):
+    g = load_golden(name)
+    w = orc.sample_affine(g["mu_w"], g["rho_w"], g["eps_w"])
+    assert allclose(w, g["w"])
+    b = None
+    if "mu_b" in g:
+        b = orc.sample_affine(g["mu_b"], g["rho_b"], g["eps_b"])
+        assert allclose(b, g["b"])
+    assert allclose(orc.linear(g["x"], w, b), g["y"])
+
+
+@pytest.mark.parametrize("name", LINEAR)
+def test_linear_kl_and_grads(name):
+    g = load_golden(name)
+    pm, ps = float(g["prior_mu"]), float(g["prior_sigma"])
+    tensors = [(g["mu_w"], g["rho_w"], pm, ps)]
+    if "mu_b" in g:
+        tensors.append((g["mu_b"], g["rho_b"], pm, ps))
+    for (mu, rho, _, _), want in zip(tensors, g["kl_parts"]):
+        assert abs(orc.kl_sum(mu, rho, pm, ps) / mu.size - want) <= 1e-5 * (1 + abs(want))
+    assert abs(orc.kl_divergence(tensors, float(g["n_batches"])) - float(g["kl"])) <= 1e-5 * (1 + abs(float(g["kl"])))
+    # backward: loss = sum(y * gy) + KL  (make_golden.linear_case)
+    gw = g["gy"].T.astype(np.float64) @ g["x"].astype(np.float64)
+    gmu_s, grho_s = orc.sample_affine_bwd(gw.astype(np.float32), g["rho_w"], g["eps_w"])
+    T = len(tensors)
+    gmu_k, grho_k = orc.kl_bwd(g["mu_w"], g["rho_w"], pm, ps, 1.0 / (g["mu_w"].size * T * float(g["n_batches"])))
+    assert np.allclose(gmu_s + gmu_k, g["g_mu_w"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(grho_s + grho_k, g["g_rho_w"], rtol=1e-4, atol=1e-5)
+    w = orc.sample_affine(g["mu_w"], g["rho_w"], g["eps_w"])
+    assert np.allclose(g["gy"].astype(np.float64) @ w.astype(np.float64), g["g_x"], rtol=1e-4, atol=1e-5)
+    if "mu_b" in g:
+        gb = g["gy"].sum(0)
+        gmu_s, grho_s = orc.sample_affine_bwd(gb, g["rho_b"], g["eps_b"])
+        gmu_k, grho_k = orc.kl_bwd(g["mu_b"], g["rho_b"], pm, ps, 1.0 / (g["mu_b"].size * T * float(g["n_batches"])))
+        assert np.allclose(gmu_s + gmu_k, g["g_mu_b"], rtol=1e-4, atol=1e-5)
+        assert np.allclose(grho_s + grho_k, g["g_rho_b"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", CONV)
+def test_conv2d_forward_and_kl(name):
+    g = load_golden(name)
+    sh, sw, ph, pw, dh, dw, groups = [int(v) for v in g["conv"]]
+    w = orc.sample_affine(g["mu_w"], g["rho_w"], g["eps_w"])
+    assert allclose(w, g["w"])
+    b = orc.sample_affine(g["mu_b"], g["rho_b"], g["eps_b"]) if "mu_b" in g else None
+    y = orc.conv2d(g["x"], w, b, (sh, sw), (ph, pw), (dh, dw), groups)
+    assert y.shape == g["y"].shape
+    assert allclose(y, g["y"])
+    tensors = [(g["mu_w"], g["rho_w"], 0.0, 0.1)]
+    if "mu_b" in g:
+        tensors.append((g["mu_b"], g["rho_b"], 0.0, 0.1))
+    assert abs(orc.kl_divergence(tensors, 1.0) - float(g["kl"])) <= 1e-5 * (1 + abs(float(g["kl"])))
+
+
+def test_conv_128_regenerated_from_seed():
+    g = load_golden("conv_128_128_k3_p1")
+    cin, cout, k, batch, hw = [int(v) for v in g["shape"]]
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    mu_w, rho_w, mu_b, rho_b = seeded.posterior(gen, (cout, cin, k, k))
+    x = torch.randn(batch, cin, hw, hw, generator=gen)
+    (ew, eb), = seeded.eps_like_reference(int(g["eps_seed"]), [((cout, cin, k, k), (cout,))])[0]
+    w = orc.sample_affine(mu_w.numpy(), rho_w.numpy(), ew.numpy())
+    b = orc.sample_affine(mu_b.numpy(), rho_b.numpy(), eb.numpy())
+    y = orc.conv2d(x.numpy(), w, b, (1, 1), (1, 1), (1, 1), 1)
+    assert allclose(y, g["y"])
+    kl = orc.kl_divergence([(mu_w.numpy(), rho_w.numpy(), 0.0, 0.1), (mu_b.numpy(), rho_b.numpy(), 0.0, 0.1)])
+    assert abs(kl - float(g["kl"])) <= 1e-5 * (1 + abs(float(g["kl"])))
+
+
+def test_mnist_pretrained_net_kl():
+    """KLDivergence of the shipped MNIST net = 0.20435977."""
+    g = load_golden("linear_mnist_pretrained")
+    c = load_golden("conv_mnist_pretrained")
+    tensors = [(c["mu_w"], c["rho_w"], 0.0, 0.1), (c["mu_b"], c["rho_b"], 0.0, 0.1),
+               (g["mu_w"], g["rho_w"], 0.0, 0.1), (g["mu_b"], g["rho_b"], 0.0, 0.1)]
+    for (mu, rho, pm, ps), want in zip(tensors, g["kl_parts_net"]):
+        assert abs(orc.kl_sum(mu, rho, pm, ps) / mu.size - want) <= 1e-5 * (1 + abs(want))
+    assert abs(orc.kl_divergence(tensors) - float(g["kl_net"])) <= 1e-5
+
+
+def test_north_star_mlp_two_samples():
+    """784-1200-1200-10, batch 512, 2 MC samples: oracle MC loop vs the reference."""
+    g = load_golden("mlp_784_1200_1200_10")
+    post = seeded.mlp_posteriors((784, 1200, 1200, 10), seed=int(g["param_seed"]))
+    x = seeded.mlp_input(512, 784, seed=int(g["x_seed"])).numpy()
+    shapes = [(tuple(p[0].shape), tuple(p[2].shape)) for p in post]
+    eps = seeded.eps_like_reference(int(g["eps_seed"]), shapes, samples=2)
+    layers = []
+    for j, (mw, rw, mb, rb) in enumerate(post):
+        layers.append(('linear', mw.numpy(), rw.numpy(), mb.numpy(), rb.numpy()))
+        if j < len(post) - 1:
+            layers.append(('relu',))
+    eps_np = [[(ew.numpy(), eb.numpy()) for ew, eb in per] for per in eps]
+    ys = orc.mc_forward(layers, x, eps_np)
+    # output rms is 36 here: 1e-5 relative to the output scale (conftest.allclose_scaled)
+    assert allclose_scaled(ys[0], g["y0"]) and allclose_scaled(ys[1], g["y1"])
+    assert allclose_scaled((ys[0] + ys[1]) / 2, g["pred_mean"])
+    tensors = []
+    for mw, rw, mb, rb in post:
+        tensors += [(mw.numpy(), rw.numpy(), 0.0, 0.1), (mb.numpy(), rb.numpy(), 0.0, 0.1)]
+    assert abs(orc.kl_divergence(tensors) - float(g["kl"])) <= 1e-5 * (1 + float(g["kl"]))
+    for (mu, rho, pm, ps), want in zip(tensors, g["kl_parts"]):
+        assert abs(orc.kl_sum(mu, rho, pm, ps) / mu.size - want) <= 1e-5 * (1 + abs(want))
