@@ -1,0 +1,130 @@
+"""ctypes binding of libbnn_hip.so (C-ABI in include/bnn_hip.h).
+
+The library is the product's only compute path for CUDA (HIP) tensors.  There is
+no fallback: if it is missing or a call fails, `BnnHipError` is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbnn_hip.so")
+
+F32, BF16 = 0, 1
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
+FLAG_RELU = 1
+
+
+class BnnHipError(RuntimeError):
+    pass
+
+
+class Rng(ctypes.Structure):
+    """bnn_rng_t"""
+    _fields_ = [("seed", ctypes.c_uint64),
+                ("stream", ctypes.c_uint32),
+                ("sample0", ctypes.c_uint32),
+                ("epoch_host", ctypes.c_uint32),
+                ("epoch_dev_delta", ctypes.c_int32),
+                ("epoch_dev", ctypes.c_void_p)]
+
+
+class KlTensor(ctypes.Structure):
+    """bnn_kl_tensor_t"""
+    _fields_ = [("mu", ctypes.c_void_p),
+                ("rho", ctypes.c_void_p),
+                ("n", ctypes.c_int64),
+                ("prior_mu", ctypes.c_float),
+                ("prior_sigma", ctypes.c_float)]
+
+
+class Conv2dShape(ctypes.Structure):
+    """bnn_conv2d_shape_t"""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("B", "C", "H", "W", "O", "KH", "KW", "stride_h", "stride_w", "pad_h", "pad_w",
+                 "dil_h", "dil_w", "groups")]
+
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f = ctypes.c_float
+_rngp = ctypes.POINTER(Rng)
+
+# name -> (restype, argtypes); every symbol include/bnn_hip.h declares.
+SIGNATURES = {
+    "bnn_abi_version": (_int, []),
+    "bnn_arch": (ctypes.c_char_p, []),
+    "bnn_last_error": (ctypes.c_char_p, []),
+    "bnn_launch_count": (ctypes.c_uint64, []),
+    "bnn_sample_affine_eps": (_int, [_p, _p, _p, _p, _i64, _int, _p]),
+    "bnn_sample_affine_philox": (_int, [_p, _p, _p, _i64, _int, _i64, _int, _rngp, _p]),
+    "bnn_eps_philox": (_int, [_p, _i64, _int, _i64, _rngp, _p]),
+    "bnn_sigma": (_int, [_p, _p, _i64, _p]),
+    "bnn_sample_affine_bwd": (_int, [_p, _i64, _p, _p, _i64, _rngp, _i64, _int, _p, _p, _int, _p]),
+    "bnn_rng_advance": (_int, [_p, ctypes.c_uint32, _p]),
+    "bnn_kl_workspace_bytes": (_i64, [_int]),
+    "bnn_kl_forward": (_int, [ctypes.POINTER(KlTensor), _int, _f, _p, _p, _p]),
+    "bnn_kl_backward": (_int, [ctypes.POINTER(KlTensor), _int, _f, _p, ctypes.POINTER(_p),
+                               ctypes.POINTER(_p), _int, _p]),
+    "bnn_linear_forward_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64,
+                                          _i64, _int, _rngp, _rngp, _int, _int, _p]),
+    "bnn_linear_forward": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,
+                                  _int, _int, _int, _p]),
+    "bnn_conv2d_forward_sampled": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64,
+                                          ctypes.POINTER(Conv2dShape), _int, _rngp, _rngp, _int, _int, _p]),
+    "bnn_conv2d_forward": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape),
+                                  _int, _int, _int, _p]),
+    "bnn_mc_sum": (_int, [_p, _i64, _int, _i64, _f, _p, _int, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libbnn_hip.so (after torch, so that its libamdhip64.so.7 dependency binds to
+    the HIP runtime torch already loaded).  Raises BnnHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BnnHipError(
+            "libbnn_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C bayesianneuralnetworks_amd/csrc`. There is no fallback path." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise BnnHipError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().bnn_last_error().decode("utf-8", "replace")
+        raise BnnHipError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda_f32(t, name):
+    if not t.is_cuda:
+        raise BnnHipError("%s must be a CUDA/HIP tensor" % name)
+    if t.dtype != torch.float32:
+        raise BnnHipError("%s must be float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise BnnHipError("%s must be contiguous" % name)

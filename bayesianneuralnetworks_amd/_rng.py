@@ -1,0 +1,89 @@
+"""Host side of the eps stream (RNG contract in include/bnn_hip.h).
+
+The reference draws eps from torch's global generator (pytorch_bayesian/nn/core.py:45).
+Here every draw is addressed by (seed, tensor stream, MC sample, epoch): counter-based, so
+the fused GEMM, the standalone sampler, the backward pass and every GPU of a sharded MC
+run regenerate identical eps without ever storing it.
+"""
+import itertools
+import threading
+
+import torch
+
+_stream_ids = itertools.count(1)
+_lock = threading.Lock()
+
+
+def new_stream_id():
+    """A tensor-stream id (< 65536), handed out in construction order so that every rank
+    of a multi-GPU run that builds the same model gets the same ids."""
+    with _lock:
+        return next(_stream_ids) & 0xFFFF
+
+
+class EpsGenerator:
+    """seed + draw counter.  `epoch_host` advances once per draw call; `epoch_dev` is a
+    device word a captured graph bumps itself (bnn_rng_advance) so replays differ."""
+
+    def __init__(self):
+        self._seed = None
+        self._torch_seed = None
+        self.epoch_host = 0
+        self._epoch_dev = {}
+
+    def manual_seed(self, seed):
+        self._seed = int(seed) & (2 ** 64 - 1)
+        self._torch_seed = torch.initial_seed()
+        self.epoch_host = 0
+        for t in self._epoch_dev.values():
+            t.zero_()
+        return self
+
+    @property
+    def seed(self):
+        # Follow torch.manual_seed(): a new torch seed re-keys and restarts the stream.
+        ts = torch.initial_seed()
+        if self._seed is None or ts != self._torch_seed:
+            self._seed = ts & (2 ** 64 - 1)
+            self._torch_seed = ts
+            self.epoch_host = 0
+        return self._seed
+
+    def next_epoch(self):
+        _ = self.seed
+        e = self.epoch_host
+        self.epoch_host = (self.epoch_host + 1) & 0xFFFFFFFF
+        return e
+
+    def epoch_dev(self, device):
+        key = (device.type, device.index)
+        t = self._epoch_dev.get(key)
+        if t is None:
+            t = torch.zeros(4, dtype=torch.int32, device=device)
+            self._epoch_dev[key] = t
+        return t
+
+
+default_generator = EpsGenerator()
+
+
+def manual_seed(seed):
+    """Seed the eps stream (and restart its draw counter)."""
+    default_generator.manual_seed(seed)
+
+
+class DrawKey:
+    """Everything needed to re-create one draw of one tensor."""
+    __slots__ = ("seed", "stream", "sample0", "nsamples", "epoch_host", "epoch_dev_delta")
+
+    def __init__(self, seed, stream, sample0, nsamples, epoch_host, epoch_dev_delta=0):
+        self.seed = seed
+        self.stream = stream
+        self.sample0 = sample0
+        self.nsamples = nsamples
+        self.epoch_host = epoch_host
+        self.epoch_dev_delta = epoch_dev_delta
+
+    def last_sample(self):
+        return DrawKey(self.seed, self.stream, self.sample0 + self.nsamples - 1, 1,
+                       self.epoch_host, self.epoch_dev_delta)

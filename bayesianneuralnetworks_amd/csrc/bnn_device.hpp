@@ -1,0 +1,158 @@
+// bnn_device.hpp -- device-side building blocks shared by every kernel of
+// libbnn_hip.so: Philox4x32-10, the Box-Muller eps draw, sigma = 1e-10 + softplus(rho).
+// gfx950 (CDNA4) only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bnn_hip.h"
+
+namespace bnn {
+
+// ----- host-side plumbing -------------------------------------------------------
+void set_error(const char *fmt, ...);
+void count_launch();
+int check_launch(const char *what);
+
+// Device view of a bnn_rng_t.
+struct RngDev {
+    uint32_t key0, key1;       // seed lo / hi
+    uint32_t stream_hi;        // stream << 16
+    uint32_t sample0;
+    uint32_t epoch_host;
+    int32_t epoch_dev_delta;
+    const uint32_t *epoch_dev;
+};
+
+static inline RngDev make_rng(const bnn_rng_t *r)
+{
+    RngDev d{};
+    if (r) {
+        d.key0 = (uint32_t)r->seed;
+        d.key1 = (uint32_t)(r->seed >> 32);
+        d.stream_hi = r->stream << 16;
+        d.sample0 = r->sample0;
+        d.epoch_host = r->epoch_host;
+        d.epoch_dev_delta = r->epoch_dev_delta;
+        d.epoch_dev = r->epoch_dev;
+    }
+    return d;
+}
+
+static inline int check_rng(const bnn_rng_t *r, int nsamples)
+{
+    if (!r) return BNN_E_NULL;
+    if (r->stream > 0xFFFFu) return BNN_E_RANGE;
+    if ((uint64_t)r->sample0 + (uint64_t)nsamples > 0x10000ull) return BNN_E_RANGE;
+    return BNN_OK;
+}
+
+// ----- Philox4x32-10 --------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        uint4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ uint32_t rng_epoch_dev(const RngDev &r)
+{
+    uint32_t e = r.epoch_dev ? __builtin_nontemporal_load(r.epoch_dev) : 0u;
+    return e + (uint32_t)r.epoch_dev_delta;
+}
+
+__device__ __forceinline__ float u01(uint32_t x)
+{
+    return ((float)(x >> 8) + 0.5f) * 0x1p-24f;
+}
+
+// One Box-Muller pair.  v_sin_f32 / v_cos_f32 take their argument in revolutions,
+// so sin(2 pi u) is evaluated on the exact u (no 2*pi rounding).  ln via the
+// accurate ocml logf: near u -> 1 the native log2 loses the relative accuracy
+// r = sqrt(-2 ln u) needs.
+__device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float &z0, float &z1)
+{
+    const float ua = u01(xa), ub = u01(xb);
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * logf(ua));
+    z0 = r * __builtin_amdgcn_cosf(ub);
+    z1 = r * __builtin_amdgcn_sinf(ub);
+}
+
+// The four eps values of Philox block `block` (elements 4*block .. 4*block+3).
+__device__ __forceinline__ float4 eps4(const RngDev &r, uint32_t epoch_dev, uint32_t block,
+                                       uint32_t sample)
+{
+    const uint4 x = philox4x32_10(make_uint4(block, r.stream_hi | (sample & 0xFFFFu),
+                                             r.epoch_host, epoch_dev), r.key0, r.key1);
+    float4 z;
+    box_muller(x.x, x.y, z.x, z.y);
+    box_muller(x.z, x.w, z.z, z.w);
+    return z;
+}
+
+__device__ __forceinline__ float eps1(const RngDev &r, uint32_t epoch_dev, uint64_t elem,
+                                      uint32_t sample)
+{
+    const float4 z = eps4(r, epoch_dev, (uint32_t)(elem >> 2), sample);
+    const uint32_t j = (uint32_t)elem & 3u;
+    return j == 0 ? z.x : j == 1 ? z.y : j == 2 ? z.z : z.w;
+}
+
+// sigma = 1e-10 + softplus(rho), torch semantics (beta 1, threshold 20).
+// log1p(e) = log(u) * e / (u - 1), u = 1 + e  (exact-rounding trick; = e when u == 1),
+// on the native exp2/log2 units: absolute error < 1e-7 * sigma + 1e-16, far inside 1e-5.
+__device__ __forceinline__ float sigma_fast(float rho)
+{
+    const float e = __expf(rho);
+    const float u = 1.0f + e;
+    const float d = u - 1.0f;
+    float sp = (d == 0.0f) ? e : __logf(u) * __fdividef(e, d);
+    sp = rho > 20.0f ? rho : sp;
+    return 1e-10f + sp;
+}
+
+// Same value through the accurate ocml routines (used where ln(sigma) is taken: KL).
+__device__ __forceinline__ float sigma_accurate(float rho)
+{
+    const float sp = rho > 20.0f ? rho : log1pf(expf(rho));
+    return 1e-10f + sp;
+}
+
+// d softplus / d rho (torch: 1 above the threshold).
+__device__ __forceinline__ float dsoftplus(float rho)
+{
+    return rho > 20.0f ? 1.0f : __fdividef(1.0f, 1.0f + __expf(-rho));
+}
+
+// fp32 -> bf16 bits, round-to-nearest-even, NaN kept NaN (v_cvt_pk_bf16_f32).
+__device__ __forceinline__ uint16_t f2bf(float v)
+{
+    const __bf16 h = (__bf16)v;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace bnn

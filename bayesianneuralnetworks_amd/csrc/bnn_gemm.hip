@@ -1,0 +1,531 @@
+// bnn_gemm.hip -- K2: the contraction that consumes the posterior draw.
+//
+//   y[s] = A[s] . W_s^T + b_s          A: dense rows (linear) or im2col of an NCHW tensor
+//   W_s  = mu + sigma(rho) * eps_s     drawn INSIDE the B-operand loader, never stored
+//
+// One "NT" MFMA GEMM (both operands K-contiguous) written for gfx950:
+//   * v_mfma_f32_16x16x4_f32 (exact fp32) or v_mfma_f32_16x16x32_bf16 (fp32 accumulate);
+//   * LDS tiles are [rows][4 chunks of 16 B]; MFMA lane (i = l & 15, q = l >> 4) reads
+//     chunk q of row i with one ds_read_b128.  The k order inside a tile is therefore a
+//     permutation of the natural one -- the same permutation for A and B, so the sum is
+//     unchanged.  Chunks are XOR-swizzled by h((row >> 2) & 3), h = {0, 2, 3, 1}, which makes
+//     every ds_read_b128 lane group hit 16 distinct 16-B slots (conflict-free, derived in
+//     DESIGN.md);
+//   * the B loader fetches mu / rho with 16-B loads, runs Philox4x32-10 + Box-Muller and
+//     softplus in registers and writes the drawn weights to LDS (fp32 or bf16);
+//   * global -> register prefetch of tile k+1 is issued before the MFMAs of tile k,
+//     sampled and written to the other LDS buffer after them: one barrier per tile;
+//   * all MC samples of a layer run in ONE grid (sample = part of the block index), and
+//     the block index is decoded XCD-aware: workgroups that share a (mu, rho) column
+//     panel have equal blockIdx % 8, i.e. share one XCD's L2.
+#include "bnn_device.hpp"
+
+namespace bnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { A_DENSE = 0, A_IM2COL = 1 };
+enum { B_PLAIN = 0, B_SAMPLED = 1 };
+
+struct GemmParams {
+    // A operand
+    const float *A;
+    int64_t a_sample_stride;
+    int64_t lda;
+    // im2col geometry (A_IM2COL)
+    int32_t C, H, W, OH, OW, KH, KW, sh, sw, ph, pw, dh, dw, Cg;
+    // B operand
+    const float *Bw;            // plain weights (N_total, K)
+    int64_t b_sample_stride;
+    const float *mu;            // sampled weights
+    const float *rho;
+    // bias: plain (bias) or sampled (mu_b, rho_b)
+    const float *bias;
+    int64_t bias_sample_stride;
+    const float *mu_b;
+    const float *rho_b;
+    // output
+    float *Y;
+    int64_t y_sample_stride;
+    int64_t ldy;
+    int32_t O;                  // conv: total output channels
+    // extents: per group M x N x K
+    int32_t M, N, K;
+    int32_t S, G;
+    int32_t ntn, ntm;           // tiles
+    int32_t flags;
+    int32_t vecA, vecB;         // 16-B loads legal
+    RngDev rng_w, rng_b;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk)
+{
+    // h = {0, 2, 3, 1} packed two bits per entry
+    return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+}
+
+template <int BM, int BN, int WM, int WN, int A_MODE, int B_MODE, int COMPUTE>
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const GemmParams p)
+{
+    constexpr int NT = WM * WN * 64;
+    constexpr int KPC = (COMPUTE == BNN_COMPUTE_F32) ? 4 : 8;   // k per 16-B chunk
+    constexpr int BK = 4 * KPC;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16x16");
+    constexpr int A_CHUNKS = BM * 4, B_CHUNKS = BN * 4;
+    constexpr int A_PER = (A_CHUNKS + NT - 1) / NT, B_PER = (B_CHUNKS + NT - 1) / NT;
+
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * (A_CHUNKS + B_CHUNKS)];
+    uint4 *As0 = lds, *Bs0 = lds + 2 * A_CHUNKS;
+
+    // ---- block decode (XCD-aware) -------------------------------------------------
+    const int L = blockIdx.x;
+    const int xcd = L & 7, i_in = L >> 3;
+    const int per_panel = p.ntm * p.S;
+    const int panel = (i_in / per_panel) * 8 + xcd;          // panel = (group, n-tile)
+    if (panel >= p.ntn * p.G) return;
+    const int rem = i_in % per_panel;
+    const int mt = rem % p.ntm, s = rem / p.ntm;
+    const int g = panel / p.ntn, nt = panel % p.ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const uint32_t sample = p.rng_w.sample0 + (uint32_t)s;
+    uint32_t edev_w = 0;
+    if constexpr (B_MODE == B_SAMPLED) edev_w = rng_epoch_dev(p.rng_w);
+
+    const float *Ab = p.A + (int64_t)s * p.a_sample_stride;
+    const int64_t nrow0 = (int64_t)g * p.N;                  // first weight row of this group
+
+    // ---- per-thread chunk ownership -------------------------------------------------
+    // A chunk id -> (row, c); rows are fixed across the K loop.
+    int64_t a_off[A_PER];       // dense: row offset; im2col: image base offset
+    int a_ih0[A_PER], a_iw0[A_PER];
+    bool a_ok[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int id = tid + i * NT;
+        const int row = id >> 2;
+        const int m = m0 + row;
+        a_ok[i] = (id < A_CHUNKS) && (m < p.M);
+        a_off[i] = 0; a_ih0[i] = 0; a_iw0[i] = 0;
+        if (a_ok[i]) {
+            if constexpr (A_MODE == A_DENSE) {
+                a_off[i] = (int64_t)m * p.lda;
+            } else {
+                const int ow = m % p.OW, t = m / p.OW;
+                const int oh = t % p.OH, b = t / p.OH;
+                a_off[i] = ((int64_t)b * p.C + (int64_t)g * p.Cg) * p.H * p.W;
+                a_ih0[i] = oh * p.sh - p.ph;
+                a_iw0[i] = ow * p.sw - p.pw;
+            }
+        }
+    }
+
+    // staging registers
+    float av[A_PER][KPC];
+    float bm[B_PER][KPC], br[B_PER][KPC];
+
+    auto load_A = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int id = tid + i * NT;
+            const int c = id & 3;
+            const int kb = k0 + c * KPC;
+#pragma unroll
+            for (int j = 0; j < KPC; ++j) av[i][j] = 0.f;
+            if (!a_ok[i]) continue;
+            if constexpr (A_MODE == A_DENSE) {
+                if (p.vecA && kb + KPC <= p.K) {
+#pragma unroll
+                    for (int v = 0; v < KPC / 4; ++v) {
+                        const float4 t = *reinterpret_cast<const float4 *>(Ab + a_off[i] + kb + 4 * v);
+                        av[i][4 * v] = t.x; av[i][4 * v + 1] = t.y; av[i][4 * v + 2] = t.z; av[i][4 * v + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KPC; ++j)
+                        if (kb + j < p.K) av[i][j] = Ab[a_off[i] + kb + j];
+                }
+            } else {
+                const int khw = p.KH * p.KW;
+#pragma unroll
+                for (int j = 0; j < KPC; ++j) {
+                    const int k = kb + j;
+                    if (k < p.K) {
+                        const int ci = k / khw, r = k % khw;
+                        const int kh = r / p.KW, kw = r % p.KW;
+                        const int ih = a_ih0[i] + kh * p.dh, iw = a_iw0[i] + kw * p.dw;
+                        if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                            av[i][j] = Ab[a_off[i] + ((int64_t)ci * p.H + ih) * p.W + iw];
+                    }
+                }
+            }
+        }
+    };
+
+    auto load_B = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int id = tid + i * NT;
+            const int row = id >> 2, c = id & 3;
+            const int n = n0 + row;
+            const int kb = k0 + c * KPC;
+#pragma unroll
+            for (int j = 0; j < KPC; ++j) { bm[i][j] = 0.f; br[i][j] = 0.f; }
+            if (id >= B_CHUNKS || n >= p.N) continue;
+            const int64_t e0 = (nrow0 + n) * (int64_t)p.K + kb;
+            const float *src_m = (B_MODE == B_SAMPLED) ? p.mu : p.Bw + (int64_t)s * p.b_sample_stride;
+            if (p.vecB && kb + KPC <= p.K) {
+#pragma unroll
+                for (int v = 0; v < KPC / 4; ++v) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src_m + e0 + 4 * v);
+                    bm[i][4 * v] = t.x; bm[i][4 * v + 1] = t.y; bm[i][4 * v + 2] = t.z; bm[i][4 * v + 3] = t.w;
+                    if constexpr (B_MODE == B_SAMPLED) {
+                        const float4 u = *reinterpret_cast<const float4 *>(p.rho + e0 + 4 * v);
+                        br[i][4 * v] = u.x; br[i][4 * v + 1] = u.y; br[i][4 * v + 2] = u.z; br[i][4 * v + 3] = u.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KPC; ++j)
+                    if (kb + j < p.K) {
+                        bm[i][j] = src_m[e0 + j];
+                        if constexpr (B_MODE == B_SAMPLED) br[i][j] = p.rho[e0 + j];
+                    }
+            }
+        }
+    };
+
+    // draw the weights of the staged B chunks (in place: bm <- w)
+    auto sample_B = [&](int k0) {
+        if constexpr (B_MODE == B_SAMPLED) {
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int id = tid + i * NT;
+                const int row = id >> 2, c = id & 3;
+                const int n = n0 + row;
+                const int kb = k0 + c * KPC;
+                if (id >= B_CHUNKS || n >= p.N || kb >= p.K) continue;
+                const int64_t e0 = (nrow0 + n) * (int64_t)p.K + kb;
+                if (p.vecB && kb + KPC <= p.K) {
+#pragma unroll
+                    for (int v = 0; v < KPC / 4; ++v) {
+                        const float4 z = eps4(p.rng_w, edev_w, (uint32_t)((e0 >> 2) + v), sample);
+                        bm[i][4 * v] = fmaf(sigma_fast(br[i][4 * v]), z.x, bm[i][4 * v]);
+                        bm[i][4 * v + 1] = fmaf(sigma_fast(br[i][4 * v + 1]), z.y, bm[i][4 * v + 1]);
+                        bm[i][4 * v + 2] = fmaf(sigma_fast(br[i][4 * v + 2]), z.z, bm[i][4 * v + 2]);
+                        bm[i][4 * v + 3] = fmaf(sigma_fast(br[i][4 * v + 3]), z.w, bm[i][4 * v + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KPC; ++j)
+                        if (kb + j < p.K)
+                            bm[i][j] = fmaf(sigma_fast(br[i][j]), eps1(p.rng_w, edev_w, (uint64_t)(e0 + j), sample), bm[i][j]);
+                }
+            }
+        }
+    };
+
+    auto pack = [&](const float (&v)[KPC]) -> uint4 {
+        uint4 o;
+        if constexpr (COMPUTE == BNN_COMPUTE_F32) {
+            o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]);
+            o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+        } else {
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        }
+        return o;
+    };
+
+    auto store_tiles = [&](int buf) {
+        uint4 *As = As0 + buf * A_CHUNKS, *Bs = Bs0 + buf * B_CHUNKS;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int id = tid + i * NT;
+            if (id < A_CHUNKS) {
+                const int row = id >> 2, c = id & 3;
+                As[row * 4 + swz(row, c)] = pack(av[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int id = tid + i * NT;
+            if (id < B_CHUNKS) {
+                const int row = id >> 2, c = id & 3;
+                Bs[row * 4 + swz(row, c)] = pack(bm[i]);
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    const int fi = lane & 15, fq = lane >> 4;
+
+    load_A(0);
+    load_B(0);
+    sample_B(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_A((kt + 1) * BK);
+            load_B((kt + 1) * BK);
+        }
+        const uint4 *As = As0 + buf * A_CHUNKS, *Bs = Bs0 + buf * B_CHUNKS;
+        uint4 af[TM], bf[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int row = wm * WTM + a * 16 + fi;
+            af[a] = As[row * 4 + swz(row, fq)];
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int row = wn * WTN + b * 16 + fi;
+            bf[b] = Bs[row * 4 + swz(row, fq)];
+        }
+        if constexpr (COMPUTE == BNN_COMPUTE_F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const uint32_t ua = j == 0 ? af[a].x : j == 1 ? af[a].y : j == 2 ? af[a].z : af[a].w;
+                        const uint32_t ub = j == 0 ? bf[b].x : j == 1 ? bf[b].y : j == 2 ? bf[b].z : bf[b].w;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua), __uint_as_float(ub),
+                                                                         acc[a][b], 0, 0, 0);
+                    }
+        } else {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
+                                                                        __builtin_bit_cast(bf16x8, bf[b]),
+                                                                        acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            sample_B((kt + 1) * BK);
+            store_tiles(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias (drawn per column), activation, store -------------------------
+    uint32_t edev_b = 0;
+    const bool sampled_bias = (p.mu_b != nullptr);
+    if (sampled_bias) edev_b = rng_epoch_dev(p.rng_b);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn * WTN + b * 16 + fi;
+        if (n >= p.N) continue;
+        const int64_t ng = nrow0 + n;
+        float bias = 0.f;
+        if (sampled_bias)
+            bias = fmaf(sigma_fast(p.rho_b[ng]), eps1(p.rng_b, edev_b, (uint64_t)ng, p.rng_b.sample0 + (uint32_t)s), p.mu_b[ng]);
+        else if (p.bias)
+            bias = p.bias[(int64_t)s * p.bias_sample_stride + ng];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * WTM + a * 16 + fq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[a][b][r] + bias;
+                if (p.flags & BNN_FLAG_RELU) v = fmaxf(v, 0.f);
+                float *Yb = p.Y + (int64_t)s * p.y_sample_stride;
+                if constexpr (A_MODE == A_DENSE) {
+                    Yb[(int64_t)m * p.ldy + ng] = v;
+                } else {
+                    const int hw = p.OH * p.OW;
+                    const int bimg = m / hw, pix = m % hw;
+                    Yb[((int64_t)bimg * p.O + ng) * hw + pix] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct TileCfg { int bm, bn; };
+
+template <int BM, int BN, int WM, int WN, int AM, int BMODE, int CP>
+static void launch_cfg(GemmParams &p, hipStream_t st)
+{
+    p.ntm = (p.M + BM - 1) / BM;
+    p.ntn = (p.N + BN - 1) / BN;
+    const int panels = p.ntn * p.G;
+    const int64_t grid = (int64_t)8 * ((panels + 7) / 8) * p.ntm * p.S;
+    hipLaunchKernelGGL((k_gemm_nt<BM, BN, WM, WN, AM, BMODE, CP>), dim3((unsigned)grid), dim3(WM * WN * 64), 0, st, p);
+}
+
+// Tile choice: big tiles amortise the weight draw over more rows; small ones fill the
+// 256 CUs when the problem is small.  (Round 1: three shapes; tuning is tracked in DESIGN.md.)
+template <int AM, int BMODE, int CP>
+static void launch_select(GemmParams &p, hipStream_t st)
+{
+    const int64_t tiles_big = (int64_t)((p.M + 255) / 256) * ((p.N + 79) / 80) * p.S * p.G;
+    if (p.N <= 16) {
+        launch_cfg<64, 16, 4, 1, AM, BMODE, CP>(p, st);
+    } else if (p.M >= 256 && p.N >= 80 && tiles_big >= 128) {
+        launch_cfg<256, 80, 8, 1, AM, BMODE, CP>(p, st);
+    } else {
+        launch_cfg<64, 64, 2, 2, AM, BMODE, CP>(p, st);
+    }
+}
+
+template <int AM>
+static int dispatch(GemmParams &p, bool sampled, int compute, hipStream_t st, const char *who)
+{
+    if (compute == BNN_COMPUTE_F32) {
+        if (sampled) launch_select<AM, B_SAMPLED, BNN_COMPUTE_F32>(p, st);
+        else launch_select<AM, B_PLAIN, BNN_COMPUTE_F32>(p, st);
+    } else if (compute == BNN_COMPUTE_BF16) {
+        if (sampled) launch_select<AM, B_SAMPLED, BNN_COMPUTE_BF16>(p, st);
+        else launch_select<AM, B_PLAIN, BNN_COMPUTE_BF16>(p, st);
+    } else {
+        set_error("%s: unknown compute mode %d", who, compute);
+        return BNN_E_DTYPE;
+    }
+    return check_launch(who);
+}
+
+static inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+static inline bool al4(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 3u) == 0; }
+
+static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
+                         const float *w, int64_t w_sample_stride, const float *b, int64_t b_sample_stride,
+                         const float *mu_w, const float *rho_w, const float *mu_b, const float *rho_b,
+                         float *y, int64_t y_sample_stride, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                         int nsamples, const bnn_rng_t *rng_w, const bnn_rng_t *rng_b, bool sampled,
+                         int compute, int flags, void *stream, const char *who)
+{
+    if (!x || !y || (sampled ? (!mu_w || !rho_w) : !w)) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (sampled && ((mu_b == nullptr) != (rho_b == nullptr))) { set_error("%s: mu_b / rho_b must both be given or both NULL", who); return BNN_E_NULL; }
+    if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldy < N) { set_error("%s: bad extent (M=%lld N=%lld K=%lld S=%d ldx=%lld ldy=%lld)", who, (long long)M, (long long)N, (long long)K, nsamples, (long long)ldx, (long long)ldy); return BNN_E_SHAPE; }
+    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || N * K > ((int64_t)1 << 34)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    if (!al4(x) || !al4(y)) { set_error("%s: misaligned pointer", who); return BNN_E_ALIGN; }
+    if (sampled) {
+        int rc = check_rng(rng_w, nsamples);
+        if (rc) { set_error("%s: bad rng_w", who); return rc; }
+        if (mu_b) { rc = check_rng(rng_b, nsamples); if (rc) { set_error("%s: bad rng_b", who); return rc; } }
+    }
+    if (M == 0) return BNN_OK;
+    GemmParams p{};
+    p.A = x; p.a_sample_stride = x_sample_stride; p.lda = ldx;
+    p.Bw = w; p.b_sample_stride = w_sample_stride; p.mu = mu_w; p.rho = rho_w;
+    p.bias = sampled ? nullptr : b; p.bias_sample_stride = b_sample_stride;
+    p.mu_b = sampled ? mu_b : nullptr; p.rho_b = sampled ? rho_b : nullptr;
+    p.Y = y; p.y_sample_stride = y_sample_stride; p.ldy = ldy; p.O = (int32_t)N;
+    p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.G = 1; p.flags = flags;
+    p.vecA = al16(x) && (ldx % 4 == 0) && (x_sample_stride % 4 == 0);
+    p.vecB = (K % 4 == 0) && (sampled ? (al16(mu_w) && al16(rho_w)) : (al16(w) && w_sample_stride % 4 == 0));
+    if (sampled) { p.rng_w = make_rng(rng_w); p.rng_b = make_rng(mu_b ? rng_b : nullptr); }
+    return dispatch<A_DENSE>(p, sampled, compute, (hipStream_t)stream, who);
+}
+
+static int conv_common(const float *x, int64_t x_sample_stride, const float *w, int64_t w_sample_stride,
+                       const float *b, int64_t b_sample_stride, const float *mu_w, const float *rho_w,
+                       const float *mu_b, const float *rho_b, float *y, int64_t y_sample_stride,
+                       const bnn_conv2d_shape_t *sh, int nsamples, const bnn_rng_t *rng_w,
+                       const bnn_rng_t *rng_b, bool sampled, int compute, int flags, void *stream,
+                       const char *who)
+{
+    if (!x || !y || !sh || (sampled ? (!mu_w || !rho_w) : !w)) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (sampled && ((mu_b == nullptr) != (rho_b == nullptr))) { set_error("%s: mu_b / rho_b must both be given or both NULL", who); return BNN_E_NULL; }
+    if (sh->B < 0 || sh->C < 1 || sh->H < 1 || sh->W < 1 || sh->O < 1 || sh->KH < 1 || sh->KW < 1 ||
+        sh->stride_h < 1 || sh->stride_w < 1 || sh->pad_h < 0 || sh->pad_w < 0 || sh->dil_h < 1 || sh->dil_w < 1 ||
+        sh->groups < 1 || nsamples < 1) { set_error("%s: bad shape", who); return BNN_E_SHAPE; }
+    // conv.py:15-18: channels must be divisible by groups
+    if (sh->C % sh->groups != 0 || sh->O % sh->groups != 0) { set_error("%s: channels must be divisible by groups", who); return BNN_E_SHAPE; }
+    const int64_t OH = ((int64_t)sh->H + 2 * sh->pad_h - (int64_t)sh->dil_h * (sh->KH - 1) - 1) / sh->stride_h + 1;
+    const int64_t OW = ((int64_t)sh->W + 2 * sh->pad_w - (int64_t)sh->dil_w * (sh->KW - 1) - 1) / sh->stride_w + 1;
+    if (OH < 1 || OW < 1) { set_error("%s: empty output (kernel larger than padded input)", who); return BNN_E_SHAPE; }
+    const int64_t M = (int64_t)sh->B * OH * OW;
+    const int64_t Cg = sh->C / sh->groups, Ng = sh->O / sh->groups;
+    const int64_t K = Cg * sh->KH * sh->KW;
+    if (M > 0x7FFFFFFF || K > 0x7FFFFFFF || (int64_t)sh->O * K > ((int64_t)1 << 34)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    if (sampled) {
+        int rc = check_rng(rng_w, nsamples);
+        if (rc) { set_error("%s: bad rng_w", who); return rc; }
+        if (mu_b) { rc = check_rng(rng_b, nsamples); if (rc) { set_error("%s: bad rng_b", who); return rc; } }
+    }
+    if (M == 0) return BNN_OK;
+    GemmParams p{};
+    p.A = x; p.a_sample_stride = x_sample_stride; p.lda = 0;
+    p.C = sh->C; p.H = sh->H; p.W = sh->W; p.OH = (int32_t)OH; p.OW = (int32_t)OW; p.KH = sh->KH; p.KW = sh->KW;
+    p.sh = sh->stride_h; p.sw = sh->stride_w; p.ph = sh->pad_h; p.pw = sh->pad_w; p.dh = sh->dil_h; p.dw = sh->dil_w;
+    p.Cg = (int32_t)Cg;
+    p.Bw = w; p.b_sample_stride = w_sample_stride; p.mu = mu_w; p.rho = rho_w;
+    p.bias = sampled ? nullptr : b; p.bias_sample_stride = b_sample_stride;
+    p.mu_b = sampled ? mu_b : nullptr; p.rho_b = sampled ? rho_b : nullptr;
+    p.Y = y; p.y_sample_stride = y_sample_stride; p.ldy = 0; p.O = sh->O;
+    p.M = (int32_t)M; p.N = (int32_t)Ng; p.K = (int32_t)K; p.S = nsamples; p.G = sh->groups; p.flags = flags;
+    p.vecA = 0;
+    p.vecB = (K % 4 == 0) && (sampled ? (al16(mu_w) && al16(rho_w)) : (al16(w) && w_sample_stride % 4 == 0));
+    if (sampled) { p.rng_w = make_rng(rng_w); p.rng_b = make_rng(mu_b ? rng_b : nullptr); }
+    return dispatch<A_IM2COL>(p, sampled, compute, (hipStream_t)stream, who);
+}
+
+}  // namespace bnn
+
+using namespace bnn;
+
+extern "C" {
+
+int bnn_linear_forward_sampled(const float *x, int64_t x_sample_stride, int64_t ldx,
+                               const float *mu_w, const float *rho_w, const float *mu_b,
+                               const float *rho_b, float *y, int64_t y_sample_stride, int64_t ldy,
+                               int64_t M, int64_t N, int64_t K, int nsamples, const bnn_rng_t *rng_w,
+                               const bnn_rng_t *rng_b, int compute, int flags, void *stream)
+{
+    return linear_common(x, x_sample_stride, ldx, nullptr, 0, nullptr, 0, mu_w, rho_w, mu_b, rho_b, y,
+                         y_sample_stride, ldy, M, N, K, nsamples, rng_w, rng_b, true, compute, flags,
+                         stream, "bnn_linear_forward_sampled");
+}
+
+int bnn_linear_forward(const float *x, int64_t x_sample_stride, int64_t ldx, const float *w,
+                       int64_t w_sample_stride, const float *b, int64_t b_sample_stride, float *y,
+                       int64_t y_sample_stride, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                       int nsamples, int compute, int flags, void *stream)
+{
+    return linear_common(x, x_sample_stride, ldx, w, w_sample_stride, b, b_sample_stride, nullptr, nullptr,
+                         nullptr, nullptr, y, y_sample_stride, ldy, M, N, K, nsamples, nullptr, nullptr,
+                         false, compute, flags, stream, "bnn_linear_forward");
+}
+
+int bnn_conv2d_forward_sampled(const float *x, int64_t x_sample_stride, const float *mu_w,
+                               const float *rho_w, const float *mu_b, const float *rho_b, float *y,
+                               int64_t y_sample_stride, const bnn_conv2d_shape_t *shape, int nsamples,
+                               const bnn_rng_t *rng_w, const bnn_rng_t *rng_b, int compute, int flags,
+                               void *stream)
+{
+    return conv_common(x, x_sample_stride, nullptr, 0, nullptr, 0, mu_w, rho_w, mu_b, rho_b, y,
+                       y_sample_stride, shape, nsamples, rng_w, rng_b, true, compute, flags, stream,
+                       "bnn_conv2d_forward_sampled");
+}
+
+int bnn_conv2d_forward(const float *x, int64_t x_sample_stride, const float *w, int64_t w_sample_stride,
+                       const float *b, int64_t b_sample_stride, float *y, int64_t y_sample_stride,
+                       const bnn_conv2d_shape_t *shape, int nsamples, int compute, int flags,
+                       void *stream)
+{
+    return conv_common(x, x_sample_stride, w, w_sample_stride, b, b_sample_stride, nullptr, nullptr,
+                       nullptr, nullptr, y, y_sample_stride, shape, nsamples, nullptr, nullptr, false,
+                       compute, flags, stream, "bnn_conv2d_forward");
+}
+
+}  // extern "C"

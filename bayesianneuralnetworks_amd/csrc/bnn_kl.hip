@@ -1,0 +1,247 @@
+// bnn_kl.hip -- K3: closed-form KL( N(mu, sigma(rho)^2) || N(mu_p, sigma_p^2) ) summed per
+// tensor, all tensors of a model in ONE launch, plus its backward.
+//
+// HBM-bound reduction: 8 algorithmic bytes per posterior scalar (mu, rho), 16-byte loads,
+// wave64 shuffle tree -> LDS -> one double partial per workgroup; a second, single-
+// workgroup kernel adds the partials in a fixed order (bitwise reproducible, no float
+// atomics) and forms the reference's mean-of-means / n_batches scalar.
+#include "bnn_device.hpp"
+
+namespace bnn {
+
+constexpr int kKlThreads = 256;
+constexpr int kKlPerThread = 16;                       // 4 x float4
+constexpr int kKlChunk = kKlThreads * kKlPerThread;    // 4096 scalars per workgroup
+constexpr int kKlMaxPerLaunch = 64;
+constexpr int kKlMaxTensors = 128;
+
+struct KlTensorDev {
+    const float *mu;
+    const float *rho;
+    float *g_mu;      // backward only
+    float *g_rho;     // backward only
+    int64_t n;
+    float prior_mu, prior_sigma;
+    int32_t first_block;   // first workgroup of this tensor within the launch
+    float scale;           // backward: 1 / (n * ntensors * n_batches)
+};
+struct KlLaunch {
+    KlTensorDev t[kKlMaxPerLaunch];
+    int32_t ntensors;
+    int32_t partial_base;  // index of this launch's first partial in the workspace
+};
+struct KlFinal {
+    int32_t first[kKlMaxTensors + 1];  // partial ranges
+    int64_t n[kKlMaxTensors];
+    int32_t ntensors;
+    float n_batches;
+};
+
+__device__ __forceinline__ float kl_elem(float mu, float rho, float pm, float inv_ps)
+{
+    const float sg = sigma_accurate(rho);
+    const float r0 = sg * inv_ps;
+    const float vr = r0 * r0;
+    const float t0 = (mu - pm) * inv_ps;
+    return 0.5f * (vr + t0 * t0 - 1.0f - logf(vr));
+}
+
+__device__ __forceinline__ int find_tensor(const KlLaunch &L, int block)
+{
+    int t = 0;
+    for (int i = 1; i < L.ntensors; ++i)
+        if (block >= L.t[i].first_block) t = i;
+    return t;
+}
+
+__global__ __launch_bounds__(kKlThreads) void k_kl_partial(KlLaunch L, double *__restrict__ partials)
+{
+    __shared__ double red[kKlThreads / 64];
+    const int t = find_tensor(L, blockIdx.x);
+    const KlTensorDev T = L.t[t];
+    const int64_t base = (int64_t)(blockIdx.x - T.first_block) * kKlChunk;
+    const float inv_ps = 1.0f / T.prior_sigma;
+    const bool vec = ((reinterpret_cast<uintptr_t>(T.mu) | reinterpret_cast<uintptr_t>(T.rho)) & 15u) == 0;
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < kKlPerThread / 4; ++it) {
+        const int64_t e = base + ((int64_t)it * kKlThreads + threadIdx.x) * 4;
+        if (vec && e + 4 <= T.n) {
+            const float4 m = *reinterpret_cast<const float4 *>(T.mu + e);
+            const float4 r = *reinterpret_cast<const float4 *>(T.rho + e);
+            acc += kl_elem(m.x, r.x, T.prior_mu, inv_ps);
+            acc += kl_elem(m.y, r.y, T.prior_mu, inv_ps);
+            acc += kl_elem(m.z, r.z, T.prior_mu, inv_ps);
+            acc += kl_elem(m.w, r.w, T.prior_mu, inv_ps);
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (e + j < T.n) acc += kl_elem(T.mu[e + j], T.rho[e + j], T.prior_mu, inv_ps);
+        }
+    }
+    double d = wave_sum((double)acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kKlThreads / 64; ++w) s += red[w];
+        partials[L.partial_base + blockIdx.x] = s;
+    }
+}
+
+// One workgroup: per tensor, add its partials in a fixed order; then the scalar of
+// KLDivergence.forward (loss.py:38): mean over tensors of (sum_t / n_t), / n_batches.
+__global__ __launch_bounds__(kKlThreads) void k_kl_final(KlFinal F, const double *__restrict__ partials,
+                                                         float *__restrict__ out)
+{
+    __shared__ double red[kKlThreads / 64];
+    __shared__ double total;
+    if (threadIdx.x == 0) total = 0.0;
+    __syncthreads();
+    for (int t = 0; t < F.ntensors; ++t) {
+        double a = 0.0;
+        for (int i = F.first[t] + threadIdx.x; i < F.first[t + 1]; i += kKlThreads) a += partials[i];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < kKlThreads / 64; ++w) s += red[w];
+            out[t] = (float)s;
+            total += (double)(float)(s / (double)F.n[t]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[F.ntensors] = (float)((total / (double)F.ntensors) / (double)F.n_batches);
+}
+
+__global__ __launch_bounds__(kKlThreads) void k_kl_backward(KlLaunch L, const float *__restrict__ upstream,
+                                                            int accumulate)
+{
+    const int t = find_tensor(L, blockIdx.x);
+    const KlTensorDev T = L.t[t];
+    const int64_t base = (int64_t)(blockIdx.x - T.first_block) * kKlChunk;
+    const float up = upstream ? upstream[0] : 1.0f;
+    const float sc = T.scale * up;
+    const float inv_ps2 = 1.0f / (T.prior_sigma * T.prior_sigma);
+#pragma unroll
+    for (int it = 0; it < kKlPerThread; ++it) {
+        const int64_t e = base + (int64_t)it * kKlThreads + threadIdx.x;
+        if (e < T.n) {
+            const float mu = T.mu[e], rho = T.rho[e];
+            const float sg = sigma_accurate(rho);
+            const float gm = sc * (mu - T.prior_mu) * inv_ps2;
+            const float gr = sc * (sg * inv_ps2 - 1.0f / sg) * dsoftplus(rho);
+            if (accumulate) {
+                T.g_mu[e] += gm;
+                T.g_rho[e] += gr;
+            } else {
+                T.g_mu[e] = gm;
+                T.g_rho[e] = gr;
+            }
+        }
+    }
+}
+
+static inline int64_t chunks_of(int64_t n) { return n == 0 ? 1 : (n + kKlChunk - 1) / kKlChunk; }
+
+static int validate(const bnn_kl_tensor_t *tensors, int ntensors, const char *who)
+{
+    if (!tensors) { set_error("%s: NULL tensor list", who); return BNN_E_NULL; }
+    if (ntensors < 1 || ntensors > kKlMaxTensors) { set_error("%s: ntensors must be in [1, %d]", who, kKlMaxTensors); return ntensors < 1 ? BNN_E_SHAPE : BNN_E_UNSUPPORTED; }
+    int64_t blocks = 0;
+    for (int t = 0; t < ntensors; ++t) {
+        if (!tensors[t].mu || !tensors[t].rho) { set_error("%s: tensor %d NULL", who, t); return BNN_E_NULL; }
+        if (tensors[t].n < 1) { set_error("%s: tensor %d empty", who, t); return BNN_E_SHAPE; }
+        if (!(tensors[t].prior_sigma > 0.f)) { set_error("%s: tensor %d prior_sigma <= 0", who, t); return BNN_E_RANGE; }
+        blocks += chunks_of(tensors[t].n);
+    }
+    if (blocks > 0x7FFFFFFF) { set_error("%s: too many elements", who); return BNN_E_RANGE; }
+    return BNN_OK;
+}
+
+}  // namespace bnn
+
+using namespace bnn;
+
+extern "C" {
+
+int64_t bnn_kl_workspace_bytes(int ntensors)
+{
+    (void)ntensors;
+    // One double per 4096-scalar chunk; sized for 2^31 scalars in total plus one chunk
+    // of slack per tensor.  (Callers that know their model may pass exactly
+    // 8 * sum_t ceil(n_t / 4096) bytes.)
+    return 8 * ((int64_t)(1ll << 31) / kKlChunk + kKlMaxTensors);
+}
+
+int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches, float *out,
+                   void *workspace, void *stream)
+{
+    int rc = validate(tensors, ntensors, "bnn_kl_forward");
+    if (rc) return rc;
+    if (!out || !workspace) { set_error("bnn_kl_forward: NULL out / workspace"); return BNN_E_NULL; }
+    if (!(n_batches > 0.f)) { set_error("bnn_kl_forward: n_batches <= 0"); return BNN_E_RANGE; }
+    hipStream_t st = (hipStream_t)stream;
+    double *partials = reinterpret_cast<double *>(workspace);
+    KlFinal F{};
+    F.ntensors = ntensors;
+    F.n_batches = n_batches;
+    int32_t pbase = 0;
+    for (int g0 = 0; g0 < ntensors; g0 += kKlMaxPerLaunch) {
+        KlLaunch L{};
+        const int cnt = ntensors - g0 < kKlMaxPerLaunch ? ntensors - g0 : kKlMaxPerLaunch;
+        L.ntensors = cnt;
+        L.partial_base = pbase;
+        int32_t blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const bnn_kl_tensor_t &s = tensors[g0 + i];
+            L.t[i].mu = s.mu; L.t[i].rho = s.rho; L.t[i].g_mu = nullptr; L.t[i].g_rho = nullptr;
+            L.t[i].n = s.n; L.t[i].prior_mu = s.prior_mu; L.t[i].prior_sigma = s.prior_sigma;
+            L.t[i].first_block = blocks; L.t[i].scale = 0.f;
+            F.first[g0 + i] = pbase + blocks;
+            F.n[g0 + i] = s.n;
+            blocks += (int32_t)chunks_of(s.n);
+        }
+        hipLaunchKernelGGL(k_kl_partial, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
+        rc = check_launch("bnn_kl_forward(partial)");
+        if (rc) return rc;
+        pbase += blocks;
+    }
+    F.first[ntensors] = pbase;
+    hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(kKlThreads), 0, st, F, partials, out);
+    return check_launch("bnn_kl_forward(final)");
+}
+
+int bnn_kl_backward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches,
+                    const float *upstream, float *const *g_mu, float *const *g_rho, int accumulate,
+                    void *stream)
+{
+    int rc = validate(tensors, ntensors, "bnn_kl_backward");
+    if (rc) return rc;
+    if (!g_mu || !g_rho) { set_error("bnn_kl_backward: NULL gradient lists"); return BNN_E_NULL; }
+    if (!(n_batches > 0.f)) { set_error("bnn_kl_backward: n_batches <= 0"); return BNN_E_RANGE; }
+    for (int t = 0; t < ntensors; ++t)
+        if (!g_mu[t] || !g_rho[t]) { set_error("bnn_kl_backward: tensor %d NULL gradient", t); return BNN_E_NULL; }
+    hipStream_t st = (hipStream_t)stream;
+    for (int g0 = 0; g0 < ntensors; g0 += kKlMaxPerLaunch) {
+        KlLaunch L{};
+        const int cnt = ntensors - g0 < kKlMaxPerLaunch ? ntensors - g0 : kKlMaxPerLaunch;
+        L.ntensors = cnt;
+        L.partial_base = 0;
+        int32_t blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const bnn_kl_tensor_t &s = tensors[g0 + i];
+            L.t[i].mu = s.mu; L.t[i].rho = s.rho; L.t[i].g_mu = g_mu[g0 + i]; L.t[i].g_rho = g_rho[g0 + i];
+            L.t[i].n = s.n; L.t[i].prior_mu = s.prior_mu; L.t[i].prior_sigma = s.prior_sigma;
+            L.t[i].first_block = blocks;
+            L.t[i].scale = (float)(1.0 / ((double)s.n * (double)ntensors * (double)n_batches));
+            blocks += (int32_t)chunks_of(s.n);
+        }
+        hipLaunchKernelGGL(k_kl_backward, dim3(blocks), dim3(kKlThreads), 0, st, L, upstream, accumulate);
+        rc = check_launch("bnn_kl_backward");
+        if (rc) return rc;
+    }
+    return BNN_OK;
+}
+
+}  // extern "C"

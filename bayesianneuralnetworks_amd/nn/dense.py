@@ -1,0 +1,234 @@
+"""Dense Bayesian layers (pytorch_bayesian/nn/dense.py).
+
+NormalLinear is the hot path: on a CUDA/HIP input its forward is ONE fused kernel
+(bnn_linear_forward_sampled): eps draw + w = mu + softplus(rho) * eps in the B-operand
+loader of an MFMA GEMM.  The other classes (Flipout, multivariate, evidential, MC-dropout)
+are outside the HIP scope and run as PyTorch-ROCm ops with the
+reference's semantics so that its examples keep working.
+"""
+import math
+
+import torch
+from torch.nn import init
+from torch.distributions import Normal
+from torch.distributions.multivariate_normal import MultivariateNormal
+
+from .. import _mc, ops
+from .._rng import default_generator
+from . import _settings
+from .container import BayesianModule
+from .core import WeightNormal, WeightMultivariateNormal
+
+
+class BayesianLinear(BayesianModule):
+    """dense.py:9-24: allocates weight (out, in) and bias (out) posteriors of type `weight`."""
+
+    def __init__(self, in_features, out_features, bias, weight, prior, bias_prior=None):
+        super().__init__(in_features, out_features, prior, bias_prior)
+        self.weight = weight(out_features, in_features)
+        if bias:
+            self.bias = weight(out_features)
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        pass
+
+
+def _init_normal_posterior(layer):
+    """dense.py:34-42 / conv.py:53-61: kaiming-uniform means, rho ~ N(-2, 0.15)."""
+    init.kaiming_uniform_(layer.weight.mean, a=math.sqrt(5))
+    init.normal_(layer.weight.scale, -2.0, 0.15)
+    if layer.bias is not None:
+        fan_in, _ = init._calculate_fan_in_and_fan_out(layer.weight.mean)
+        bound = 1 / math.sqrt(fan_in)
+        init.uniform_(layer.bias.mean, -bound, bound)
+        init.normal_(layer.bias.scale, -2.0, 0.15)
+
+
+class _NormalSampling:
+    """sample()/.sampled shared by NormalLinear and NormalConvNd (dense.py:46-54, conv.py:65-73)."""
+
+    compute = None      # None -> module-wide default (nn.set_compute)
+
+    def sample(self, nsamples=1, sample0=0):
+        # weight first, then bias (dense.py:47-51); one epoch for the layer's draw
+        epoch = default_generator.next_epoch() if self.weight.mean.is_cuda else None
+        self.weight.sample(nsamples, sample0, epoch)
+        if self.bias is not None:
+            self.bias.sample(nsamples, sample0, epoch)
+
+    @property
+    def sampled(self):
+        return (self.weight.sampled, self.bias.sampled if self.bias is not None else None)
+
+    @sampled.setter
+    def sampled(self, value):
+        w, b = value
+        self.weight.sampled = w
+        if self.bias is not None and b is not None:
+            self.bias.sampled = b
+
+    def _compute_mode(self):
+        return self.compute or _settings.get_compute()
+
+    def _mc_plan(self, x, sample):
+        """-> (S, sample0, shared_x, rows_per_sample) for the current MC context."""
+        ctx = _mc.current()
+        if ctx is None or ctx.samples == 1:
+            S, s0 = 1, (ctx.sample0 if ctx else 0)
+            shared, per = True, x.shape[0]
+        else:
+            S, s0 = ctx.samples, ctx.sample0
+            if x.shape[0] == ctx.base_batch:
+                shared, per = True, x.shape[0]
+            elif x.shape[0] == ctx.base_batch * S:
+                shared, per = False, ctx.base_batch
+            else:
+                raise RuntimeError("mc_batched: layer input has %d rows, expected %d or %d"
+                                   % (x.shape[0], ctx.base_batch, ctx.base_batch * S))
+        if sample:
+            self.sample(S, s0)
+        return S, s0, shared, per
+
+    def _keys(self, S):
+        kw = self.weight.draw_key
+        kb = self.bias.draw_key if self.bias is not None else None
+        if kw is None or (self.bias is not None and kb is None):
+            return None
+        if kw.nsamples != S:
+            if S == 1:
+                return kw.last_sample(), (kb.last_sample() if kb is not None else None)
+            raise RuntimeError("sample=False: the recorded draw has %d MC samples, this call needs %d"
+                               % (kw.nsamples, S))
+        return kw, kb
+
+
+class NormalLinear(_NormalSampling, BayesianLinear):
+    """dense.py:27-60."""
+
+    def __init__(self, in_features, out_features, bias=True, prior=Normal(0, .1)):
+        super().__init__(in_features, out_features, bias, WeightNormal, prior)
+
+    def reset_parameters(self):
+        _init_normal_posterior(self)
+        self.sample()                                                   # dense.py:44
+
+    def forward(self, x, sample=True):
+        if not x.is_cuda:
+            # CPU-resident module: the reference's own op sequence (dense.py:56-60)
+            if sample:
+                self.sample()
+            return torch.nn.functional.linear(x, *self.sampled)
+        if x.dim() == 1:
+            return self.forward(x.unsqueeze(0), sample).squeeze(0)
+        S, _, shared, per = self._mc_plan(x, sample)
+        lead = x.shape[1:-1]
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K) if shared else x.reshape(S, -1, K)
+        keys = self._keys(S)
+        mode = self._compute_mode()
+        if keys is not None:
+            y = ops.linear_sampled(x2, self.weight.mean, self.weight.scale,
+                                   self.bias.mean if self.bias is not None else None,
+                                   self.bias.scale if self.bias is not None else None,
+                                   keys[0], keys[1], shared, mode)
+        else:
+            # weights were set explicitly (parity mode / user-assigned .sampled)
+            w, b = self.sampled
+            y = ops.linear_plain(x2, w.unsqueeze(0).expand(S, -1, -1), None if b is None else
+                                 b.unsqueeze(0).expand(S, -1), shared, mode)
+        return y.reshape(S * per, *lead, y.shape[-1])
+
+
+class FlipoutNormalLinear(NormalLinear):
+    """dense.py:63-83: y = x mu^T + ((x * S) sigma^T) * R with random sign vectors; no bias."""
+
+    def __init__(self, in_features, out_features, prior=Normal(0, .1)):
+        super().__init__(in_features, out_features, False, prior)
+
+    def sample(self, *unused):
+        dev = self.weight.device
+        self.R = (torch.rand(self.weight.size(0), device=dev) - .5).sign()
+        self.S = (torch.rand(self.weight.size(1), device=dev) - .5).sign()
+
+    @property
+    def sampled(self):
+        return (self.R, self.S)
+
+    def forward(self, x, sample=True):
+        if sample:
+            self.sample()
+        perturbation = torch.matmul(x * self.S, self.weight.stddev.t()) * self.R
+        # the reference hands the perturbation to F.linear as its bias argument (dense.py:83)
+        return torch.nn.functional.linear(x, self.weight.mean, perturbation)
+
+
+class MultivariateNormalLinear(BayesianLinear):
+    """dense.py:86-138 (PyTorch ops)."""
+
+    def __init__(self, in_features, out_features, bias=True, weight_prior=None, bias_prior=None):
+        if not weight_prior:
+            weight_prior = MultivariateNormal(torch.zeros(out_features, in_features),
+                                              torch.eye(in_features).repeat(out_features, 1, 1))
+        if bias and not bias_prior:
+            bias_prior = MultivariateNormal(torch.zeros(out_features), torch.eye(out_features))
+        super().__init__(in_features, out_features, bias, WeightMultivariateNormal,
+                         weight_prior, bias_prior)
+
+    @staticmethod
+    def _mask_upper(scale):
+        with torch.no_grad():
+            upper = torch.triu(torch.ones_like(scale), 1).to(torch.bool)
+            scale[upper] = -100
+
+    def reset_parameters(self):
+        _init_normal_posterior(self)
+        self._mask_upper(self.weight.scale)
+        if self.bias is not None:
+            self._mask_upper(self.bias.scale)
+        self.sample()
+
+    def sample(self):
+        self.weight.sample()
+        if self.bias is not None:
+            self.bias.sample()
+            self.sampled = (self.weight.sampled, self.bias.sampled)
+        else:
+            self.sampled = (self.weight.sampled, None)
+
+    def forward(self, x, sample=True):
+        if sample:
+            self.sample()
+        return torch.nn.functional.linear(x, *self.sampled)
+
+
+class NormalInverseGaussianLinear(BayesianModule):
+    """dense.py:141-162: evidential head, deterministic Linear(in, 4*out) + softplus splits."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__(in_features, out_features, None)
+        self.linear = torch.nn.Linear(in_features, 4 * out_features, bias)
+
+    def forward(self, x, sample=False):
+        sp = torch.nn.functional.softplus
+        gamma, upsilon, alpha, beta = torch.split(self.linear(x), self.out_channels, dim=-1)
+        upsilon = 1e-10 + sp(upsilon)
+        alpha = 1 + 1e-10 + sp(alpha)
+        beta = 1e-10 + sp(beta)
+        if not sample:
+            return (gamma, upsilon, alpha, beta)
+        return Normal(gamma.clone(), torch.sqrt(beta / (upsilon * (alpha - 1))))
+
+
+class MCDropoutLinear(BayesianModule):
+    """dense.py:165-179: dropout stays active while `sample` is true."""
+
+    def __init__(self, in_features, out_features, bias=True, drop_prob=0.5):
+        super().__init__(in_features, out_features, None)
+        self.drop_prob = drop_prob
+        self.linear = torch.nn.Linear(in_features, out_features, bias)
+
+    def forward(self, x, sample=True):
+        return torch.nn.functional.dropout(self.linear(x), self.drop_prob, sample, False)

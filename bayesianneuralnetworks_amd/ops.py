@@ -1,0 +1,453 @@
+"""Tensor-level front-end of the C-ABI (include/bnn_hip.h) with autograd.
+
+Forward passes are hand-written HIP (libbnn_hip.so).  Backward: the eps-dependent
+elementwise parts are HIP too (bnn_sample_affine_bwd, bnn_kl_backward; eps is regenerated
+from the draw key, never stored); the two plain GEMMs of a linear/conv backward go through
+torch.bmm / torch's conv backward on the GPU (library GEMMs on already-drawn weights).
+
+Every function here requires CUDA (HIP) tensors and raises BnnHipError otherwise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BnnHipError, Rng, KlTensor, Conv2dShape, ptr, stream_ptr, check, require_cuda_f32
+from ._rng import default_generator, DrawKey
+
+
+def _rng_struct(key, device):
+    r = Rng()
+    r.seed = key.seed
+    r.stream = key.stream
+    r.sample0 = key.sample0
+    r.epoch_host = key.epoch_host
+    r.epoch_dev_delta = key.epoch_dev_delta
+    r.epoch_dev = default_generator.epoch_dev(device).data_ptr()
+    return r
+
+
+def _compute_code(compute):
+    if compute in ("f32", "fp32", _lib.COMPUTE_F32):
+        return _lib.COMPUTE_F32
+    if compute in ("bf16", _lib.COMPUTE_BF16):
+        return _lib.COMPUTE_BF16
+    raise ValueError("compute must be 'f32' or 'bf16', got %r" % (compute,))
+
+
+# --------------------------------------------------------------------------- K1
+def sigma(rho):
+    """1e-10 + softplus(rho)  (WeightNormal.stddev, core.py:25-27) -- no autograd."""
+    rho = rho.detach()
+    require_cuda_f32(rho, "rho")
+    out = torch.empty_like(rho)
+    check(_lib.load().bnn_sigma(ptr(rho), ptr(out), rho.numel(), stream_ptr(rho.device)), "bnn_sigma")
+    return out
+
+
+def eps_philox(shape, key, device):
+    """The raw eps stream for `key` -> (nsamples, *shape) fp32."""
+    n = 1
+    for d in shape:
+        n *= d
+    out = torch.empty((key.nsamples,) + tuple(shape), dtype=torch.float32, device=device)
+    r = _rng_struct(key, out.device)
+    check(_lib.load().bnn_eps_philox(ptr(out), n, key.nsamples, n, ctypes.byref(r), stream_ptr(out.device)),
+          "bnn_eps_philox")
+    return out
+
+
+def _sample_affine_philox_raw(mu, rho, key, out_dtype=torch.float32):
+    require_cuda_f32(mu, "mu")
+    require_cuda_f32(rho, "rho")
+    n = mu.numel()
+    out = torch.empty((key.nsamples,) + tuple(mu.shape), dtype=out_dtype, device=mu.device)
+    r = _rng_struct(key, mu.device)
+    code = _lib.F32 if out_dtype == torch.float32 else _lib.BF16
+    check(_lib.load().bnn_sample_affine_philox(ptr(mu), ptr(rho), ptr(out), n, key.nsamples, n, code,
+                                                ctypes.byref(r), stream_ptr(mu.device)),
+          "bnn_sample_affine_philox")
+    return out
+
+
+def _sample_affine_bwd_raw(g_w, rho, n, nsamples, eps=None, key=None):
+    g_w = g_w.contiguous()
+    g_mu = torch.empty_like(rho)
+    g_rho = torch.empty_like(rho)
+    r = _rng_struct(key, rho.device) if key is not None else None
+    check(_lib.load().bnn_sample_affine_bwd(ptr(g_w), n, ptr(rho), ptr(eps), n,
+                                             ctypes.byref(r) if r is not None else None,
+                                             n, nsamples, ptr(g_mu), ptr(g_rho), 0, stream_ptr(rho.device)),
+          "bnn_sample_affine_bwd")
+    return g_mu, g_rho
+
+
+class _SampleAffineEps(torch.autograd.Function):
+    """w = mu + sigma(rho) * eps with eps supplied (parity mode)."""
+
+    @staticmethod
+    def forward(ctx, mu, rho, eps):
+        require_cuda_f32(mu, "mu")
+        require_cuda_f32(rho, "rho")
+        require_cuda_f32(eps, "eps")
+        out = torch.empty_like(mu)
+        check(_lib.load().bnn_sample_affine_eps(ptr(mu), ptr(rho), ptr(eps), ptr(out), mu.numel(), _lib.F32,
+                                                 stream_ptr(mu.device)), "bnn_sample_affine_eps")
+        ctx.save_for_backward(rho, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rho, eps = ctx.saved_tensors
+        g_mu, g_rho = _sample_affine_bwd_raw(g, rho, rho.numel(), 1, eps=eps)
+        return g_mu, g_rho, None
+
+
+class _SampleAffinePhilox(torch.autograd.Function):
+    """(S, *shape) draws of w = mu + sigma(rho) * eps(key)."""
+
+    @staticmethod
+    def forward(ctx, mu, rho, key):
+        out = _sample_affine_philox_raw(mu.detach(), rho.detach(), key)
+        ctx.save_for_backward(rho)
+        ctx.key = key
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (rho,) = ctx.saved_tensors
+        g_mu, g_rho = _sample_affine_bwd_raw(g, rho, rho.numel(), ctx.key.nsamples, key=ctx.key)
+        return g_mu, g_rho, None
+
+
+def sample_affine_eps(mu, rho, eps):
+    return _SampleAffineEps.apply(mu.contiguous(), rho.contiguous(), eps.contiguous())
+
+
+def sample_affine_philox(mu, rho, key):
+    return _SampleAffinePhilox.apply(mu.contiguous(), rho.contiguous(), key)
+
+
+# --------------------------------------------------------------------------- K2 linear
+def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, compute, relu):
+    N, K = mu_w.shape
+    S = key_w.nsamples
+    y = torch.empty((S, M, N), dtype=torch.float32, device=x2.device)
+    rw = _rng_struct(key_w, x2.device)
+    rb = _rng_struct(key_b, x2.device) if mu_b is not None else None
+    check(_lib.load().bnn_linear_forward_sampled(
+        ptr(x2), x_sample_stride, K, ptr(mu_w), ptr(rho_w), ptr(mu_b), ptr(rho_b),
+        ptr(y), M * N, N, M, N, K, S, ctypes.byref(rw), ctypes.byref(rb) if rb is not None else None,
+        compute, _lib.FLAG_RELU if relu else 0, stream_ptr(x2.device)), "bnn_linear_forward_sampled")
+    return y
+
+
+class _SampledLinear(torch.autograd.Function):
+    """y[s] = x[s] @ w_s^T + b_s, w_s / b_s drawn in-kernel (NormalLinear.forward, dense.py:56-60)."""
+
+    @staticmethod
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute):
+        # x: (M, K) shared by all samples, or (S, M, K)
+        require_cuda_f32(x, "x")
+        for t, n in ((mu_w, "weight.mean"), (rho_w, "weight.scale")):
+            require_cuda_f32(t, n)
+        if mu_b is not None:
+            require_cuda_f32(mu_b, "bias.mean")
+            require_cuda_f32(rho_b, "bias.scale")
+        M = x.shape[-2]
+        K = x.shape[-1]
+        if K != mu_w.shape[1]:
+            raise BnnHipError("linear: input has %d features, weight expects %d" % (K, mu_w.shape[1]))
+        y = _linear_sampled_raw(x, 0 if shared_x else M * K, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b,
+                                compute, False)
+        ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None)
+        ctx.key_w, ctx.key_b, ctx.shared_x = key_w, key_b, shared_x
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mu_w, rho_w, rho_b = ctx.saved_tensors
+        S = ctx.key_w.nsamples
+        gy = gy.contiguous()
+        gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
+        if ctx.needs_input_grad[0]:
+            w = _sample_affine_philox_raw(mu_w, rho_w, ctx.key_w)          # (S, N, K), HIP
+            gx = torch.bmm(gy, w)                                          # (S, M, K)
+            if ctx.shared_x:
+                gx = gx.sum(0)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            xs = x.unsqueeze(0).expand(S, -1, -1) if ctx.shared_x else x
+            gw = torch.bmm(gy.transpose(1, 2), xs)                         # (S, N, K)
+            g_mu_w, g_rho_w = _sample_affine_bwd_raw(gw, rho_w, rho_w.numel(), S, key=ctx.key_w)
+        if rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            gb = gy.sum(1)                                                 # (S, N)
+            g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None
+
+
+def linear_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute="f32"):
+    return _SampledLinear.apply(x.contiguous(), mu_w.contiguous(), rho_w.contiguous(),
+                                None if mu_b is None else mu_b.contiguous(),
+                                None if rho_b is None else rho_b.contiguous(),
+                                key_w, key_b, shared_x, _compute_code(compute))
+
+
+class _PlainLinear(torch.autograd.Function):
+    """y[s] = x[s] @ w[s]^T + b[s] with given weights (F.linear, dense.py:60)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, shared_x, compute):
+        require_cuda_f32(x, "x")
+        require_cuda_f32(w, "w")
+        S, N, K = w.shape
+        M = x.shape[-2]
+        if x.shape[-1] != K:
+            raise BnnHipError("linear: input has %d features, weight expects %d" % (x.shape[-1], K))
+        y = torch.empty((S, M, N), dtype=torch.float32, device=x.device)
+        if b is not None:
+            require_cuda_f32(b, "b")
+        check(_lib.load().bnn_linear_forward(ptr(x), 0 if shared_x else M * K, K, ptr(w), N * K, ptr(b), N,
+                                              ptr(y), M * N, N, M, N, K, S, compute, 0, stream_ptr(x.device)),
+              "bnn_linear_forward")
+        ctx.save_for_backward(x, w)
+        ctx.shared_x, ctx.has_b = shared_x, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        S = w.shape[0]
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.bmm(gy, w)
+            if ctx.shared_x:
+                gx = gx.sum(0)
+        if ctx.needs_input_grad[1]:
+            xs = x.unsqueeze(0).expand(S, -1, -1) if ctx.shared_x else x
+            gw = torch.bmm(gy.transpose(1, 2), xs)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            gb = gy.sum(1)
+        return gx, gw, gb, None, None
+
+
+def linear_plain(x, w, b, shared_x, compute="f32"):
+    return _PlainLinear.apply(x.contiguous(), w.contiguous(), None if b is None else b.contiguous(),
+                              shared_x, _compute_code(compute))
+
+
+# --------------------------------------------------------------------------- K2 conv2d
+def _conv_shape(x_shape, w_shape, stride, padding, dilation, groups):
+    sh = Conv2dShape()
+    sh.B, sh.C, sh.H, sh.W = x_shape
+    sh.O, _, sh.KH, sh.KW = w_shape
+    sh.stride_h, sh.stride_w = stride
+    sh.pad_h, sh.pad_w = padding
+    sh.dil_h, sh.dil_w = dilation
+    sh.groups = groups
+    OH = (sh.H + 2 * sh.pad_h - sh.dil_h * (sh.KH - 1) - 1) // sh.stride_h + 1
+    OW = (sh.W + 2 * sh.pad_w - sh.dil_w * (sh.KW - 1) - 1) // sh.stride_w + 1
+    return sh, OH, OW
+
+
+class _SampledConv2d(torch.autograd.Function):
+    """y[s] = conv2d(x[s], w_s, b_s, ...) as an implicit GEMM with in-kernel draws
+    (NormalConv2d.forward, conv.py:112-119)."""
+
+    @staticmethod
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, conv_args, compute):
+        require_cuda_f32(x, "x")
+        require_cuda_f32(mu_w, "weight.mean")
+        require_cuda_f32(rho_w, "weight.scale")
+        stride, padding, dilation, groups = conv_args
+        S = key_w.nsamples
+        xs = x.shape[-4:]
+        if xs[1] != mu_w.shape[1] * groups:
+            raise BnnHipError("conv2d: input has %d channels, weight expects %d" % (xs[1], mu_w.shape[1] * groups))
+        sh, OH, OW = _conv_shape(xs, mu_w.shape, stride, padding, dilation, groups)
+        if OH < 1 or OW < 1:
+            raise BnnHipError("conv2d: kernel larger than padded input")
+        y = torch.empty((S, sh.B, sh.O, OH, OW), dtype=torch.float32, device=x.device)
+        rw = _rng_struct(key_w, x.device)
+        rb = _rng_struct(key_b, x.device) if mu_b is not None else None
+        per = sh.B * sh.C * sh.H * sh.W
+        check(_lib.load().bnn_conv2d_forward_sampled(
+            ptr(x), 0 if shared_x else per, ptr(mu_w), ptr(rho_w), ptr(mu_b), ptr(rho_b), ptr(y),
+            sh.B * sh.O * OH * OW, ctypes.byref(sh), S, ctypes.byref(rw),
+            ctypes.byref(rb) if rb is not None else None, compute, 0, stream_ptr(x.device)),
+            "bnn_conv2d_forward_sampled")
+        ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None)
+        ctx.key_w, ctx.key_b, ctx.shared_x, ctx.conv_args = key_w, key_b, shared_x, conv_args
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mu_w, rho_w, rho_b = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conv_args
+        S = ctx.key_w.nsamples
+        gy = gy.contiguous()
+        gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if need_x or need_w:
+            w = _sample_affine_philox_raw(mu_w, rho_w, ctx.key_w)          # (S, O, Cg, KH, KW)
+            gxs, gws = [], []
+            for s in range(S):
+                xs_ = x if ctx.shared_x else x[s]
+                if need_x:
+                    gxs.append(torch.nn.grad.conv2d_input(xs_.shape, w[s], gy[s], stride, padding, dilation, groups))
+                if need_w:
+                    gws.append(torch.nn.grad.conv2d_weight(xs_, w[s].shape, gy[s], stride, padding, dilation, groups))
+            if need_x:
+                gx = torch.stack(gxs).sum(0) if ctx.shared_x else torch.stack(gxs)
+            if need_w:
+                gw = torch.stack(gws)
+                g_mu_w, g_rho_w = _sample_affine_bwd_raw(gw, rho_w, rho_w.numel(), S, key=ctx.key_w)
+        if rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            gb = gy.sum((1, 3, 4))
+            g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None
+
+
+def conv2d_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, stride, padding, dilation, groups,
+                   compute="f32"):
+    return _SampledConv2d.apply(x.contiguous(), mu_w.contiguous(), rho_w.contiguous(),
+                                None if mu_b is None else mu_b.contiguous(),
+                                None if rho_b is None else rho_b.contiguous(),
+                                key_w, key_b, shared_x,
+                                (tuple(stride), tuple(padding), tuple(dilation), int(groups)),
+                                _compute_code(compute))
+
+
+class _PlainConv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, shared_x, conv_args, compute):
+        require_cuda_f32(x, "x")
+        require_cuda_f32(w, "w")
+        stride, padding, dilation, groups = conv_args
+        S = w.shape[0]
+        xs = x.shape[-4:]
+        if xs[1] != w.shape[2] * groups:
+            raise BnnHipError("conv2d: input has %d channels, weight expects %d" % (xs[1], w.shape[2] * groups))
+        sh, OH, OW = _conv_shape(xs, w.shape[1:], stride, padding, dilation, groups)
+        if OH < 1 or OW < 1:
+            raise BnnHipError("conv2d: kernel larger than padded input")
+        y = torch.empty((S, sh.B, sh.O, OH, OW), dtype=torch.float32, device=x.device)
+        per = sh.B * sh.C * sh.H * sh.W
+        wper = w[0].numel()
+        check(_lib.load().bnn_conv2d_forward(ptr(x), 0 if shared_x else per, ptr(w), wper, ptr(b), sh.O, ptr(y),
+                                              sh.B * sh.O * OH * OW, ctypes.byref(sh), S, compute, 0,
+                                              stream_ptr(x.device)), "bnn_conv2d_forward")
+        ctx.save_for_backward(x, w)
+        ctx.shared_x, ctx.conv_args, ctx.has_b = shared_x, conv_args, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conv_args
+        S = w.shape[0]
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        gxs, gws = [], []
+        for s in range(S):
+            xs_ = x if ctx.shared_x else x[s]
+            if ctx.needs_input_grad[0]:
+                gxs.append(torch.nn.grad.conv2d_input(xs_.shape, w[s], gy[s], stride, padding, dilation, groups))
+            if ctx.needs_input_grad[1]:
+                gws.append(torch.nn.grad.conv2d_weight(xs_, w[s].shape, gy[s], stride, padding, dilation, groups))
+        if gxs:
+            gx = torch.stack(gxs).sum(0) if ctx.shared_x else torch.stack(gxs)
+        if gws:
+            gw = torch.stack(gws)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            gb = gy.sum((1, 3, 4))
+        return gx, gw, gb, None, None, None
+
+
+def conv2d_plain(x, w, b, shared_x, stride, padding, dilation, groups, compute="f32"):
+    return _PlainConv2d.apply(x.contiguous(), w.contiguous(), None if b is None else b.contiguous(), shared_x,
+                              (tuple(stride), tuple(padding), tuple(dilation), int(groups)),
+                              _compute_code(compute))
+
+
+# --------------------------------------------------------------------------- K3
+_kl_ws = {}
+
+
+def _kl_workspace(device):
+    key = (device.type, device.index)
+    ws = _kl_ws.get(key)
+    if ws is None:
+        nbytes = _lib.load().bnn_kl_workspace_bytes(0)
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+        _kl_ws[key] = ws
+    return ws
+
+
+def _kl_descs(mus, rhos, priors):
+    T = len(mus)
+    arr = (KlTensor * T)()
+    for i in range(T):
+        arr[i].mu = mus[i].data_ptr()
+        arr[i].rho = rhos[i].data_ptr()
+        arr[i].n = mus[i].numel()
+        arr[i].prior_mu = priors[i][0]
+        arr[i].prior_sigma = priors[i][1]
+    return arr
+
+
+class _KLNormal(torch.autograd.Function):
+    """Returns out (T + 1): per-tensor KL SUMS then the KLDivergence scalar (loss.py:16-38)."""
+
+    @staticmethod
+    def forward(ctx, n_batches, priors, *params):
+        T = len(params) // 2
+        mus = [p.detach() for p in params[:T]]
+        rhos = [p.detach() for p in params[T:]]
+        for m, r in zip(mus, rhos):
+            require_cuda_f32(m, "mean")
+            require_cuda_f32(r, "scale")
+        dev = mus[0].device
+        out = torch.empty(T + 1, dtype=torch.float32, device=dev)
+        arr = _kl_descs(mus, rhos, priors)
+        check(_lib.load().bnn_kl_forward(arr, T, float(n_batches), ptr(out), ptr(_kl_workspace(dev)),
+                                          stream_ptr(dev)), "bnn_kl_forward")
+        ctx.save_for_backward(*params)
+        ctx.n_batches, ctx.priors, ctx.T = float(n_batches), priors, T
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        # Only the scalar out[T] is differentiable here (the per-tensor sums are reported
+        # for diagnostics / the sharded all-reduce and carry no gradient).
+        params = ctx.saved_tensors
+        T = ctx.T
+        mus, rhos = params[:T], params[T:]
+        up = g_out[T:T + 1].contiguous()
+        g_mu = [torch.empty_like(m) for m in mus]
+        g_rho = [torch.empty_like(r) for r in rhos]
+        arr = _kl_descs(mus, rhos, ctx.priors)
+        gm = (ctypes.c_void_p * T)(*[t.data_ptr() for t in g_mu])
+        gr = (ctypes.c_void_p * T)(*[t.data_ptr() for t in g_rho])
+        check(_lib.load().bnn_kl_backward(arr, T, ctx.n_batches, ptr(up), gm, gr, 0, stream_ptr(up.device)),
+              "bnn_kl_backward")
+        return (None, None) + tuple(g_mu) + tuple(g_rho)
+
+
+def kl_normal(mus, rhos, priors, n_batches=1.0):
+    """priors: list of (prior_mu, prior_sigma) floats.  -> tensor (T + 1)."""
+    mus = [m.contiguous() for m in mus]
+    rhos = [r.contiguous() for r in rhos]
+    return _KLNormal.apply(n_batches, tuple(priors), *mus, *rhos)
+
+
+# --------------------------------------------------------------------------- MC reduction
+def mc_mean(y):
+    """mean over the leading MC axis: torch.stack(preds).mean(0) (examples/MNIST/uncertainty.py:50)."""
+    require_cuda_f32(y, "y")
+    S = y.shape[0]
+    n = y[0].numel()
+    out = torch.empty(y.shape[1:], dtype=torch.float32, device=y.device)
+    check(_lib.load().bnn_mc_sum(ptr(y), n, S, n, 1.0 / S, ptr(out), 0, stream_ptr(y.device)), "bnn_mc_sum")
+    return out

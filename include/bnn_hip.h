@@ -1,0 +1,201 @@
+/*
+ * bnn_hip.h -- C-ABI of libbnn_hip.so, the MI355X (gfx950) variational-layer engine.
+ *
+ * The reference (Mirko-Nava/BayesianNeuralNetworks, pytorch_bayesian 0.0.4) is
+ * pure Python and has NO FFI: its hot path is a sequence of stock torch calls.
+ * Each entry point below therefore replaces a reference *Python call site*; the
+ * citation after "replaces" is that site, relative to /root/reference/.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the
+ *     parameter is documented "host"; no allocation and no synchronisation inside
+ *     (every call is legal during hipGraph / torch.cuda.graph capture);
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - return value: 0 = success, <0 = BNN_E_* argument error (nothing launched),
+ *     >0 = the hipError_t of a failed launch; bnn_last_error() gives the text;
+ *   - tensors are dense row-major fp32 unless a dtype argument says otherwise.
+ *
+ * RNG contract (production eps source; its CPU twin is oracle/bnn_oracle.c, orc_eps4)
+ *   eps for element e of tensor-stream `stream`, MC sample `sample`:
+ *     (x0..x3) = Philox4x32-10(counter = (e / 4, (stream << 16) | sample,
+ *                                         epoch_host, epoch_dev),
+ *                              key     = (seed & 0xffffffff, seed >> 32))
+ *     u  = ((x >> 8) + 0.5) * 2^-24
+ *     z0 = r(u0) cos(2 pi u1), z1 = r(u0) sin(2 pi u1), z2, z3 likewise from x2, x3,
+ *     r(u) = sqrt(-2 ln u);   eps[e] = z[e % 4].
+ *   epoch_dev is read from device memory (*rng->epoch_dev + rng->epoch_dev_delta) so
+ *   that a replayed graph draws fresh noise: bnn_rng_advance bumps it in-stream.
+ *   The draw depends only on (seed, stream, sample, epochs, e): not on tiling,
+ *   grid size, or the number of GPUs the MC samples are sharded over.
+ */
+#ifndef BNN_HIP_H
+#define BNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNN_ABI_VERSION 1
+
+enum {
+    BNN_OK = 0,
+    BNN_E_NULL = -1,      /* required pointer is NULL */
+    BNN_E_SHAPE = -2,     /* negative / zero / inconsistent extent */
+    BNN_E_DTYPE = -3,     /* unknown dtype code */
+    BNN_E_ALIGN = -4,     /* pointer not aligned to the element size */
+    BNN_E_RANGE = -5,     /* value outside the supported range (e.g. >65535 samples) */
+    BNN_E_UNSUPPORTED = -6
+};
+
+enum { BNN_F32 = 0, BNN_BF16 = 1 };
+
+/* Compute mode of the contraction kernels. */
+enum {
+    BNN_COMPUTE_F32 = 0,  /* v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate */
+    BNN_COMPUTE_BF16 = 1  /* operands rounded to bf16 (RNE), v_mfma_f32_16x16x32_bf16, fp32 accumulate */
+};
+
+/* One eps stream (host struct, read at call time). */
+typedef struct bnn_rng {
+    uint64_t seed;
+    uint32_t stream;            /* tensor-stream id, < 65536 */
+    uint32_t sample0;           /* id of the first MC sample of this call; sample s uses sample0 + s */
+    uint32_t epoch_host;        /* host-side draw counter */
+    int32_t epoch_dev_delta;    /* added to *epoch_dev (e.g. -1 to re-create the previous replay's draw) */
+    const uint32_t *epoch_dev;  /* device word bumped by bnn_rng_advance; NULL = 0 */
+} bnn_rng_t;
+
+/* One Gaussian posterior tensor with its Gaussian prior (host struct). */
+typedef struct bnn_kl_tensor {
+    const float *mu;
+    const float *rho;
+    int64_t n;
+    float prior_mu;
+    float prior_sigma;
+} bnn_kl_tensor_t;
+
+/* ---- library / device queries ------------------------------------------- */
+int bnn_abi_version(void);
+const char *bnn_arch(void);          /* "gfx950" */
+const char *bnn_last_error(void);    /* text of the last non-zero return on this thread */
+/* Number of kernel launches issued through this library so far (tests use it to
+ * prove the HIP path ran). */
+uint64_t bnn_launch_count(void);
+
+/* ---- K1: posterior draw --------------------------------------------------
+ * replaces  WeightNormal.stddev / WeightNormal.sample
+ *           pytorch_bayesian/nn/core.py:25-27, 44-45
+ *   out = mu + (1e-10 + softplus(rho)) * eps        (softplus: beta 1, threshold 20)
+ */
+/* eps supplied by the caller (parity mode: eps from torch's CPU generator). */
+int bnn_sample_affine_eps(const float *mu, const float *rho, const float *eps,
+                          void *out, int64_t n, int out_dtype, void *stream);
+/* eps drawn in-kernel; writes `nsamples` draws, draw s at out + s * out_sample_stride
+ * elements. */
+int bnn_sample_affine_philox(const float *mu, const float *rho, void *out, int64_t n,
+                             int nsamples, int64_t out_sample_stride, int out_dtype,
+                             const bnn_rng_t *rng, void *stream);
+/* The raw eps stream (fp32), same layout as above. */
+int bnn_eps_philox(float *out, int64_t n, int nsamples, int64_t out_sample_stride,
+                   const bnn_rng_t *rng, void *stream);
+/* sigma = 1e-10 + softplus(rho)   (WeightNormal.stddev, core.py:25-27) */
+int bnn_sigma(const float *rho, float *out, int64_t n, void *stream);
+
+/* Backward of K1 (what autograd derives from core.py:44-45), summed over samples:
+ *   g_mu[e]  (+)= sum_s g_w[s][e]
+ *   g_rho[e] (+)= sum_s g_w[s][e] * eps_s[e] * sigmoid(rho[e])
+ * eps: external (eps != NULL, sample stride eps_sample_stride) or Philox (rng != NULL).
+ * accumulate != 0 adds into g_mu / g_rho instead of overwriting. */
+int bnn_sample_affine_bwd(const float *g_w, int64_t g_w_sample_stride, const float *rho,
+                          const float *eps, int64_t eps_sample_stride, const bnn_rng_t *rng,
+                          int64_t n, int nsamples, float *g_mu, float *g_rho, int accumulate,
+                          void *stream);
+
+/* epoch_dev[0] += inc, in stream order (a 1-thread kernel; graph-capturable). */
+int bnn_rng_advance(uint32_t *epoch_dev, uint32_t inc, void *stream);
+
+/* ---- K3: closed-form Gaussian KL ------------------------------------------
+ * replaces  KLDivergence.compute_kl / KLDivergence.forward
+ *           pytorch_bayesian/nn/loss.py:16-28, 30-38
+ *           (torch.distributions.kl._kl_normal_normal)
+ *   kl_e = 0.5 * (r + t - 1 - ln r),  r = (sigma/sigma_p)^2,  t = ((mu - mu_p)/sigma_p)^2
+ * out[0..ntensors-1] = per-tensor SUMS (the reference's .mean() = sum / n);
+ * out[ntensors]      = mean_t(sum_t / n_t) / n_batches   (loss.py:38).
+ * `tensors` is a host array; `workspace` needs bnn_kl_workspace_bytes(ntensors) bytes.
+ * Deterministic: fixed-order two-pass reduction, no float atomics. */
+int64_t bnn_kl_workspace_bytes(int ntensors);
+int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches,
+                   float *out, void *workspace, void *stream);
+/* Backward: for tensor t,  g_mu (+)= scale_t * (mu - mu_p)/sigma_p^2,
+ *   g_rho (+)= scale_t * (sigma/sigma_p^2 - 1/sigma) * sigmoid(rho),
+ * scale_t = *upstream (device scalar, may be NULL = 1) / (n_t * ntensors * n_batches). */
+int bnn_kl_backward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches,
+                    const float *upstream, float *const *g_mu, float *const *g_rho,
+                    int accumulate, void *stream);
+
+/* ---- K2: sampled linear ----------------------------------------------------
+ * replaces  NormalLinear.forward   pytorch_bayesian/nn/dense.py:56-60
+ *           (sample(): dense.py:46-54 -> core.py:44-45, then F.linear)
+ * and, with nsamples > 1, the MC loop of BayesianNetworkModule.forward
+ *           pytorch_bayesian/nn/container.py:32-37  for this layer.
+ *
+ *   for s in [0, nsamples):
+ *     w_s = mu_w + sigma(rho_w) * eps(rng_w, s)      (N, K)   never written to memory
+ *     b_s = mu_b + sigma(rho_b) * eps(rng_b, s)      (N)      (mu_b == NULL: no bias)
+ *     y[s] = x[s] @ w_s^T + b_s                      (M, N)
+ *   x[s] = x + s * x_sample_stride (0 = every sample reads the same input),
+ *   y[s] = y + s * y_sample_stride;  ldx / ldy = row strides in elements.
+ * flags: BNN_FLAG_RELU applies max(.,0) in the epilogue. */
+enum { BNN_FLAG_RELU = 1 };
+int bnn_linear_forward_sampled(const float *x, int64_t x_sample_stride, int64_t ldx,
+                               const float *mu_w, const float *rho_w,
+                               const float *mu_b, const float *rho_b,
+                               float *y, int64_t y_sample_stride, int64_t ldy,
+                               int64_t M, int64_t N, int64_t K, int nsamples,
+                               const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
+                               int compute, int flags, void *stream);
+/* Same contraction with the weights given (F.linear(x, w, b), dense.py:60):
+ * w[s] = w + s * w_sample_stride, b[s] = b + s * b_sample_stride (b may be NULL). */
+int bnn_linear_forward(const float *x, int64_t x_sample_stride, int64_t ldx,
+                       const float *w, int64_t w_sample_stride,
+                       const float *b, int64_t b_sample_stride,
+                       float *y, int64_t y_sample_stride, int64_t ldy,
+                       int64_t M, int64_t N, int64_t K, int nsamples,
+                       int compute, int flags, void *stream);
+
+/* ---- K2: sampled conv2d (implicit GEMM) --------------------------------------
+ * replaces  NormalConv2d.forward   pytorch_bayesian/nn/conv.py:112-119
+ *   y[s] = conv2d(x[s], w_s, b_s, stride, padding, dilation, groups), NCHW / OIHW.
+ * Implicit GEMM: M = B*OH*OW, N = O/groups, K = (C/groups)*KH*KW. */
+typedef struct bnn_conv2d_shape {
+    int32_t B, C, H, W;          /* input  (B, C, H, W) */
+    int32_t O, KH, KW;           /* weight (O, C/groups, KH, KW) */
+    int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups;
+} bnn_conv2d_shape_t;
+int bnn_conv2d_forward_sampled(const float *x, int64_t x_sample_stride,
+                               const float *mu_w, const float *rho_w,
+                               const float *mu_b, const float *rho_b,
+                               float *y, int64_t y_sample_stride,
+                               const bnn_conv2d_shape_t *shape, int nsamples,
+                               const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
+                               int compute, int flags, void *stream);
+int bnn_conv2d_forward(const float *x, int64_t x_sample_stride,
+                       const float *w, int64_t w_sample_stride,
+                       const float *b, int64_t b_sample_stride,
+                       float *y, int64_t y_sample_stride,
+                       const bnn_conv2d_shape_t *shape, int nsamples,
+                       int compute, int flags, void *stream);
+
+/* ---- MC reduction ----------------------------------------------------------
+ * replaces  torch.stack(preds).mean(0)   examples/MNIST/uncertainty.py:50
+ *   out[i] (+)= scale * sum_s y[s * y_sample_stride + i],  i < n. */
+int bnn_mc_sum(const float *y, int64_t y_sample_stride, int nsamples, int64_t n,
+               float scale, float *out, int accumulate, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNN_HIP_H */

@@ -1,0 +1,231 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol
+include/bnn_hip.h declares (no compute without a GPU), the Module surface matches the
+reference's (names, attributes, state_dict keys, traversal semantics, error behaviour)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from torch.distributions import Normal
+
+import bayesianneuralnetworks_amd as bnn
+from bayesianneuralnetworks_amd import _lib
+from bayesianneuralnetworks_amd.nn import *          # noqa: F401,F403
+from bayesianneuralnetworks_amd.prune import PruneNormal
+from bayesianneuralnetworks_amd.utils import _item_or_list, _single, _pair, _triple, apply_wb, traverse
+from conftest import ROOT, allclose, load_golden
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "bnn_hip.h")).read()
+    declared = set(re.findall(r"\b(bnn_[a-z0-9_]+)\s*\(", header))
+    declared -= {"bnn_rng", "bnn_kl_tensor", "bnn_conv2d_shape"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    # pure host queries only -- nothing is launched without a GPU
+    assert lib.bnn_abi_version() == 1
+    assert lib.bnn_arch() == b"gfx950"
+    assert lib.bnn_kl_workspace_bytes(6) > 0
+
+
+def test_argument_errors_are_reported_without_launching():
+    lib = _lib.load()
+    n0 = lib.bnn_launch_count()
+    assert lib.bnn_sample_affine_eps(None, None, None, None, 4, 0, None) == -1
+    assert b"NULL" in lib.bnn_last_error()
+    r = _lib.Rng(seed=1, stream=70000)
+    one = ctypes.c_void_p(16)
+    assert lib.bnn_eps_philox(one, 4, 1, 4, ctypes.byref(r), None) == -5
+    assert lib.bnn_linear_forward(one, 0, 4, one, 0, None, 0, one, 0, 4, 2, 0, 4, 1, 0, 0, None) == -2
+    sh = _lib.Conv2dShape(B=1, C=3, H=5, W=5, O=4, KH=3, KW=3, stride_h=1, stride_w=1, pad_h=0, pad_w=0,
+                          dil_h=1, dil_w=1, groups=2)
+    assert lib.bnn_conv2d_forward(one, 0, one, 0, None, 0, one, 0, ctypes.byref(sh), 1, 0, 0, None) == -2
+    assert b"divisible by groups" in lib.bnn_last_error()
+    assert lib.bnn_launch_count() == n0
+
+
+def test_cuda_only_ops_refuse_cpu_tensors():
+    from bayesianneuralnetworks_amd import ops
+    with pytest.raises(_lib.BnnHipError):
+        ops.sigma(torch.zeros(4))
+
+
+def test_exports_match_reference_names():
+    # pytorch_bayesian/nn/__init__.py:7-35
+    names = ['BayesianModule', 'BayesianNetworkModule', 'WeightNormal', 'WeightMultivariateNormal',
+             'BayesianLinear', 'NormalLinear', 'MultivariateNormalLinear', 'FlipoutNormalLinear',
+             'NormalInverseGaussianLinear', 'MCDropoutLinear', 'BayesianConvNd', 'NormalConvNd',
+             'NormalConv1d', 'NormalConv2d', 'NormalConv3d', 'FlipOutNormalConvNd', 'FlipOutNormalConv1d',
+             'FlipOutNormalConv2d', 'FlipOutNormalConv3d', 'MCDropoutConvNd', 'MCDropoutConv1d',
+             'MCDropoutConv2d', 'MCDropoutConv3d', 'KLDivergence', 'Entropy', 'NormalInverseGaussianLoss',
+             'NormalInverseGaussianUncertainty']
+    assert sorted(bnn.nn.__all__) == sorted(names)
+    for n in names:
+        assert hasattr(bnn.nn, n)
+    assert bnn.__version__.startswith('0.0.4')
+    import pytorch_bayesian
+    from pytorch_bayesian.nn import NormalLinear as NL
+    from pytorch_bayesian.prune import PruneNormal as PN
+    from pytorch_bayesian.utils import apply_wb as aw
+    assert NL is NormalLinear and PN is PruneNormal and aw is apply_wb
+
+
+def test_state_dict_keys_and_pretrained_shapes():
+    layer = NormalLinear(576, 10)
+    assert list(layer.state_dict().keys()) == ['weight.mean', 'weight.scale', 'bias.mean', 'bias.scale']
+    conv = NormalConv2d(64, 64, 3, padding=1, stride=2)
+    assert conv.weight.shape == (64, 64, 3, 3) and conv.bias.shape == (64,)
+    assert conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
+    assert conv.dilation == (1, 1) and conv.transposed is False and conv.groups == 1
+    g = load_golden("linear_mnist_pretrained")
+    layer.load_state_dict({'weight.mean': torch.from_numpy(g["mu_w"]), 'weight.scale': torch.from_numpy(g["rho_w"]),
+                           'bias.mean': torch.from_numpy(g["mu_b"]), 'bias.scale': torch.from_numpy(g["rho_b"])})
+    assert np.array_equal(layer.weight.mean.detach().numpy(), g["mu_w"])
+
+
+def test_weightnormal_surface():
+    # tests/test_nn/test_core.py:14-39
+    from torch.nn.parameter import Parameter
+    for shape in [(1,), (3, 4), (5, 6, 7)]:
+        wn = WeightNormal(*shape)
+        assert isinstance(wn.mean, Parameter) and isinstance(wn.scale, Parameter)
+        assert wn.mean.shape == shape and wn.shape == wn.mean.shape
+        assert wn.device == wn.mean.device and wn.requires_grad == wn.mean.requires_grad
+        assert isinstance(wn.sampled, torch.Tensor) and isinstance(wn.dist, Normal)
+        assert wn.size() == shape and wn.size(0) == shape[0]
+        torch.nn.init.constant_(wn.mean, 0)
+        torch.nn.init.constant_(wn.scale, -100)
+        wn.sample()
+        assert (wn.stddev > 0).all() and (wn.stddev ** 2 == wn.variance).all()
+        assert torch.allclose(wn.sampled, torch.zeros(shape), atol=1e-5)
+
+
+def test_cpu_resident_layers_follow_the_reference_draw_order():
+    """CPU tensors use the reference's own expression on torch's global generator
+    (core.py:45, dense.py:46-54): same seed -> the fixture's w, b, y."""
+    g = load_golden("linear_7x11")
+    layer = NormalLinear(11, 7)
+    with torch.no_grad():
+        layer.weight.mean.copy_(torch.from_numpy(g["mu_w"]))
+        layer.weight.scale.copy_(torch.from_numpy(g["rho_w"]))
+        layer.bias.mean.copy_(torch.from_numpy(g["mu_b"]))
+        layer.bias.scale.copy_(torch.from_numpy(g["rho_b"]))
+    torch.manual_seed(int(g["eps_seed"]))
+    y = layer(torch.from_numpy(g["x"]))
+    assert allclose(layer.sampled[0].detach().numpy(), g["w"])
+    assert allclose(layer.sampled[1].detach().numpy(), g["b"])
+    assert allclose(y.detach().numpy(), g["y"])
+    y2 = layer(torch.from_numpy(g["x"]), sample=False)
+    assert torch.equal(y, y2)
+
+
+class ComposableBNN(BayesianNetworkModule):
+    def __init__(self, i, o, arch):
+        super().__init__(i, o, samples=1)
+        self.arch = arch
+
+    def _forward(self, x, *a, **k):
+        return self.arch(x)
+
+
+def test_container_surface():
+    # tests/test_nn/test_container.py:16-33
+    bm = BayesianModule(3, 5, Normal(0, 1))
+    assert bm.in_channels == 3 and bm.out_channels == 5
+    assert bm.weight_prior is bm.bias_prior
+    bnm = BayesianNetworkModule(3, 5, 10)
+    assert (bnm.in_channels, bnm.out_channels, bnm.samples) == (3, 5, 10)
+    with pytest.raises(NotImplementedError):
+        bnm.forward(torch.zeros(2, 3, 5))
+
+
+def test_utils_semantics():
+    # tests/test_utils.py + tests/conftest.py:26-145
+    for ex in [(0,), (1,), (2, 3), [0], [1], [2, 3]]:
+        assert _item_or_list(ex) == (ex[0] if len(ex) == 1 else ex)
+    assert _single(2.3) == (2.3,) and _pair(1) == (1, 1) and _triple(0) == (0, 0, 0)
+    assert _pair((2, 3)) == (2, 3)
+    lin = torch.nn.Linear(3, 3)
+    assert apply_wb(lin, lambda x: None) is None
+    assert apply_wb(lin, lambda x: x.shape) == [(3, 3), (3,)]
+    nl = NormalLinear(3, 3, Normal(0, 1))        # conftest.py:91 quirk: Normal lands in `bias`
+    assert nl.bias is not None
+    assert apply_wb(nl, lambda x, type: type, pass_type=True) == ['w', 'b']
+    assert apply_wb(nl, lambda x, module: x.shape, pass_module=True) == [(3, 3), (3,)]
+    assert traverse(lin, lambda x: [x]) is None
+    assert traverse(BayesianModule(3, 3, Normal(0, 1)), lambda x: [type(x.weight_prior)]) == [Normal]
+    assert traverse(NormalLinear(3, 3, False, Normal(0, 1)), lambda x: [x.bias is not None]) == [False]
+    net = ComposableBNN(3, 4, torch.nn.Sequential(NormalLinear(3, 4), NormalLinear(4, 2), NormalLinear(2, 1)))
+    assert traverse(net, lambda x: [x.weight.shape]) == [torch.Size([4, 3]), torch.Size([2, 4]), torch.Size([1, 2])]
+    # a Bayesian layer nested in a non-listed container is skipped (utils.py:51-52)
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inner = NormalLinear(2, 2)
+    assert traverse(ComposableBNN(2, 2, Wrap()), lambda x: [1]) is None
+
+
+def test_kl_divergence_cpu_modules_and_errors():
+    # tests/test_nn/test_loss.py:23-34 and the fixture value of make_golden.linear_case
+    with pytest.raises(ValueError):
+        KLDivergence()(ComposableBNN(3, 4, torch.nn.Linear(3, 4)))
+    g = load_golden("linear_7x11")
+    layer = NormalLinear(11, 7, True, Normal(float(g["prior_mu"]), float(g["prior_sigma"])))
+    with torch.no_grad():
+        layer.weight.mean.copy_(torch.from_numpy(g["mu_w"]))
+        layer.weight.scale.copy_(torch.from_numpy(g["rho_w"]))
+        layer.bias.mean.copy_(torch.from_numpy(g["mu_b"]))
+        layer.bias.scale.copy_(torch.from_numpy(g["rho_b"]))
+    kl = KLDivergence(number_of_batches=3)(ComposableBNN(11, 7, layer))
+    assert abs(kl.item() - float(g["kl"])) < 1e-6
+
+
+def test_prune_normal_fraction():
+    # tests/test_prune.py:7-24 (passes a tensor to log_prob: the reference's int fails on torch 2.x)
+    net = ComposableBNN(3, 4, torch.nn.Sequential(NormalLinear(30, 40), NormalLinear(40, 20)))
+    before = net.traverse(lambda m: apply_wb(m, lambda x, module: x.mean.clone(), pass_module=True))
+    PruneNormal()(net, 0.5)
+    after = net.traverse(lambda m: apply_wb(m, lambda x, module: x.mean.clone(), pass_module=True))
+    frac = torch.stack([(a != b).float().mean() for b, a in zip(before, after)]).mean()
+    assert abs(frac - 0.5) < 2e-2
+    assert (net.arch[0].weight.scale == -30).float().mean() == 0.5
+
+
+def test_out_of_scope_layers_keep_reference_semantics():
+    # collapsed-posterior KATs of tests/test_nn/test_dense.py:73-95, 196-229 and test_conv.py:149-215
+    fl = FlipoutNormalLinear(5, 3)
+    torch.nn.init.constant_(fl.weight.mean, 1)
+    torch.nn.init.constant_(fl.weight.scale, -100)
+    assert allclose(fl(torch.ones(3, 5)).detach().numpy(), np.full((3, 3), 5.0))
+    fc = FlipOutNormalConv2d(3, 4, 3, padding=1)
+    torch.nn.init.constant_(fc.weight.mean, 1)
+    torch.nn.init.constant_(fc.weight.scale, -100)
+    x = torch.ones(7, 3, 10, 10)
+    want = torch.nn.functional.conv2d(x, torch.ones(4, 3, 3, 3), None, 1, 1)
+    assert allclose(fc(x).detach().numpy(), want.numpy())
+    nig = NormalInverseGaussianLinear(6, 2)
+    out = nig(torch.ones(4, 6))
+    assert len(out) == 4 and all(o.shape == (4, 2) for o in out)
+    assert isinstance(nig(torch.ones(4, 6), sample=True), Normal)
+    md = MCDropoutLinear(100, 100, drop_prob=0.3)
+    assert abs((md(torch.ones(50, 100)) == 0).float().mean() - 0.3) < 5e-2
+    mc = MCDropoutConv2d(2, 3, 3)
+    assert mc.weight is mc.conv.weight
+    mv = MultivariateNormalLinear(6, 3)
+    assert mv(torch.ones(2, 6)).shape == (2, 3) and mv.weight.scale.shape == (3, 6, 6)
+    ent = Entropy(-1)
+    with pytest.warns(RuntimeWarning):
+        ent(torch.zeros(2))
+    assert abs(ent(torch.tensor([0.5, 0.5])).item() - np.log(2)) < 1e-6
+
+
+def test_mc_batched_is_opt_in_and_cpu_uses_the_serial_loop():
+    net = ComposableBNN(3, 4, torch.nn.Sequential(NormalLinear(3, 4)))
+    assert net.mc_batched is False
+    ys = net(torch.ones(2, 3), samples=3)
+    assert isinstance(ys, list) and len(ys) == 3
+    assert isinstance(net(torch.ones(2, 3)), torch.Tensor)
