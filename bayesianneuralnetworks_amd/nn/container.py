@@ -54,14 +54,17 @@ class BayesianNetworkModule(Module):
     def _forward_batched(self, x, samples, sample0, *args, **kwargs):
         """One pass, all samples per layer launch.  Returns the list of per-sample outputs
         (views of one (S*B, ...) tensor)."""
+        return list(self._forward_batched_stacked(x, samples, sample0, *args, **kwargs).unbind(0))
+
+    def _forward_batched_stacked(self, x, samples, sample0, *args, **kwargs):
         B = x.shape[0]
         with _mc.McContext(samples, B, sample0):
             y = self._forward(x, *args, **kwargs)
         if y.shape[0] == B * samples:
-            return list(y.view(samples, B, *y.shape[1:]).unbind(0))
+            return y.view(samples, B, *y.shape[1:])
         if y.shape[0] == B:
             # no Bayesian layer saw the batch: every draw is the same deterministic output
-            return [y for _ in range(samples)]
+            return y.unsqueeze(0).expand(samples, *y.shape)
         raise RuntimeError("mc_batched: _forward returned %d rows for batch %d x %d samples"
                            % (y.shape[0], B, samples))
 
@@ -70,6 +73,6 @@ class BayesianNetworkModule(Module):
         if samples is None:
             samples = self.samples
         if self.mc_batched and x.is_cuda:
-            return torch.stack(self._forward_batched(x, samples, sample0, *args, **kwargs))
+            return self._forward_batched_stacked(x, samples, sample0, *args, **kwargs)
         out = [self._forward(x, *args, **kwargs) for _ in range(samples)]
         return torch.stack(out)

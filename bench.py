@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""bench.py -- MC-samples/sec of the 784-1200-1200-10 NormalLinear MLP at batch 512
+(BASELINE.json metric; configs[1]: bf16 operands / fp32 accumulate, 8 MC samples per forward).
+
+One step = one stochastic forward of S = 8 MC samples over one synthetic batch of 512
+(all samples of a layer in one fused sampled-GEMM launch), the Gaussian KL once, the
+predictive mean over the samples, and -- for N > 1 -- ONE all-reduce over RCCL of the packed
+[KL sums || sum of predictions] buffer.  Weak scaling: every rank runs its own 8 samples
+(sample ids rank*8 .. rank*8+7 of the same posterior), value = N * 8 * steps / time.
+
+Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel, measured live with
+events on the launch stream), `cpu_baseline` (torch-CPU port of the reference, N = 1 only),
+`f32` (same step in the exact-fp32 parity mode).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DIMS = (784, 1200, 1200, 10)
+BATCH = 512
+SAMPLES = 8
+P_SCALARS = sum(i * o + o for i, o in zip(DIMS[:-1], DIMS[1:]))          # 2 395 210
+FLOP_PER_SAMPLE = 2 * BATCH * sum(i * o for i, o in zip(DIMS[:-1], DIMS[1:]))  # 2 450 227 200
+PEAK = {"f32": 157.3, "bf16": 2500.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def posteriors(seed=0):
+    """Random-init weights of the architecture (reference init distributions, dense.py:34-42)."""
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for i, o in zip(DIMS[:-1], DIMS[1:]):
+        bound = 1.0 / i ** 0.5
+        out.append(((torch.rand(o, i, generator=gen) * 2 - 1) * bound,
+                    torch.randn(o, i, generator=gen) * 0.15 - 2.0,
+                    (torch.rand(o, generator=gen) * 2 - 1) * bound,
+                    torch.randn(o, generator=gen) * 0.15 - 2.0))
+    return out
+
+
+def build_net(dev, post):
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule
+
+    class MLP(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(DIMS[0], DIMS[-1], SAMPLES)
+            mods = []
+            for j, (mw, rw, mb, rb) in enumerate(post):
+                L = NormalLinear(mw.shape[1], mw.shape[0])
+                with torch.no_grad():
+                    L.weight.mean.copy_(mw)
+                    L.weight.scale.copy_(rw)
+                    L.bias.mean.copy_(mb)
+                    L.bias.scale.copy_(rb)
+                mods.append(L)
+                if j < len(post) - 1:
+                    mods.append(torch.nn.ReLU())
+            self.layers = torch.nn.Sequential(*mods)
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    net = MLP().to(dev)
+    net.mc_batched = True
+    return net
+
+
+class Step:
+    """One forward of S samples + KL + predictive mean, optionally captured in a HIP graph."""
+
+    def __init__(self, net, x, rank, world, use_graph):
+        from bayesianneuralnetworks_amd import ops, _lib
+        from bayesianneuralnetworks_amd._rng import default_generator
+        from bayesianneuralnetworks_amd.nn import KLDivergence
+        self.net, self.x, self.rank, self.world = net, x, rank, world
+        self.ops, self.lib, self._lib = ops, _lib.load(), _lib
+        self.gen = default_generator
+        self.kld = KLDivergence()
+        self.graph = None
+        self.packed = None
+        self.linears = [m for m in net.layers if hasattr(m, "weight")]
+        if use_graph:
+            self._capture()
+
+    def _body(self):
+        with torch.no_grad():
+            ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)   # (S, B, 10)
+            out = self.ops.kl_normal([p for L in self.linears for p in (L.weight.mean, L.bias.mean)],
+                                     [p for L in self.linears for p in (L.weight.scale, L.bias.scale)],
+                                     [(0.0, 0.1)] * (2 * len(self.linears)), 1.0)
+            pred = self.ops.mc_mean(ys)
+            # packed buffer of the one collective: [KL sums (6) , KL scalar , sum_s pred_s / S]
+            if self.packed is None:
+                self.packed = torch.empty(out.numel() + pred.numel(), device=self.x.device)
+            self.packed[:out.numel()].copy_(out)
+            self.packed[out.numel():].copy_(pred.reshape(-1))
+        return self.packed
+
+    def _capture(self):
+        dev = self.x.device
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize()
+        cell = self.gen.epoch_dev(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body()
+            # fresh noise on every replay: bump the device epoch inside the graph
+            self._lib.check(self.lib.bnn_rng_advance(self._lib.ptr(cell), 1, self._lib.stream_ptr(dev)),
+                            "bnn_rng_advance")
+        self.graph = g
+
+    def run(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._body()
+        if self.world > 1:
+            torch.distributed.all_reduce(self.packed)      # RCCL over xGMI, ~20 KB, latency-bound
+        return self.packed
+
+
+def time_steps(step, steps, warmup, world, dev):
+    for _ in range(warmup):
+        step.run()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.run()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    return dt
+
+
+def kernel_roofline(net, x, mode, dev, iters=50):
+    """Dominant kernel = the fused sampled GEMM of layer 2 (512 x 1200 x 1200, 8 samples in one
+    launch).  Average launch duration from events on the launch stream; algorithmic FLOPs."""
+    from bayesianneuralnetworks_amd import _mc
+    layer = net.layers[2]
+    h = torch.randn(SAMPLES * BATCH, DIMS[1], device=dev)
+    layer.compute = mode
+    with torch.no_grad(), _mc.McContext(SAMPLES, BATCH, 0):
+        for _ in range(5):
+            layer(h)
+        torch.cuda.synchronize(dev)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            layer(h)
+        e1.record()
+        torch.cuda.synchronize(dev)
+    layer.compute = None
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * SAMPLES * BATCH * DIMS[1] * DIMS[2]
+    ach = flops / (ms * 1e-3) / 1e12
+    # parameter bytes the launch must touch at least once: mu, rho of W and b
+    pbytes = 8.0 * (DIMS[1] * DIMS[2] + DIMS[2])
+    return {"kernel": "k_gemm_nt<sampled> layer2 512x1200x1200 x8 samples", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s", "frac": round(ach / PEAK[mode], 4),
+            "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
+            "algorithmic_flop_per_launch": flops, "algorithmic_param_bytes_per_launch": pbytes}
+
+
+def sampler_roofline(dev, iters=20):
+    """K1 alone on a working set beyond the Infinity Cache (64 Mi scalars = 768 MiB of traffic):
+    HBM-bound, 8 B read + 4 B written per scalar."""
+    from bayesianneuralnetworks_amd import ops
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    n = 64 << 20
+    mu = torch.zeros(n, device=dev)
+    rho = torch.full((n,), -2.0, device=dev)
+    key = DrawKey(1, 1, 0, 1, 0)
+    for _ in range(3):
+        ops._sample_affine_philox_raw(mu, rho, key)
+    torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops._sample_affine_philox_raw(mu, rho, key)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    gbs = 12.0 * n / (ms * 1e-3) / 1e9
+    return {"kernel": "k_sample_affine_philox 64Mi scalars", "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            "avg_launch_us": round(ms * 1e3, 1)}
+
+
+def cpu_baseline(post, x_cpu):
+    """The torch-CPU port of the reference (oracle/reference_port.py, pinned bit-for-bit to the
+    reference by tests/test_oracle_golden.py) on this machine's host cores."""
+    from oracle import reference_port as port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        for _ in range(2):
+            port.mlp_forward(x_cpu, post, SAMPLES)
+            port.kl_divergence_loss(post)
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            ys = port.mlp_forward(x_cpu, post, SAMPLES)
+            port.kl_divergence_loss(post)
+            torch.stack(ys).mean(0)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > 12.0 or n >= 60:
+                break
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": round(n * SAMPLES / dt, 2), "unit": "MC-samples/s", "cores": cores, "kind": "port",
+            "sample": "%d forwards of 8 MC samples, batch 512, + KL + predictive mean; fp32, no_grad; %.1f s; %s"
+                      % (n, dt, model)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd import _lib
+    _lib.load()                                     # fail loudly if the HIP library is missing
+    post = posteriors(0)
+    net = build_net(dev, post)
+    x_cpu = torch.randn(BATCH, DIMS[0], generator=torch.Generator().manual_seed(1))
+    x = x_cpu.to(dev)
+    bnn.manual_seed(2)
+
+    results = {}
+    for mode in ([args.dtype] + (["f32"] if args.dtype != "f32" else [])):
+        bnn.set_compute(mode)
+        step = Step(net, x, rank, world, not args.no_graph)
+        steps = args.steps if mode == args.dtype else max(10, args.steps // 4)
+        dt = time_steps(step, steps, args.warmup, world, dev)
+        results[mode] = (world * SAMPLES * steps / dt, dt / steps * 1e3, steps)
+    bnn.set_compute(args.dtype)
+
+    if rank == 0:
+        val, ms, steps = results[args.dtype]
+        line = {
+            "metric": "MC-samples/sec (node), 784-1200-1200-10 BayesianLinear MLP, batch 512",
+            "value": round(val, 1), "unit": "MC-samples/s", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: MNIST-shape 784-1200-1200-10 NormalLinear MLP, batch 512, "
+                                   "8 MC samples per forward per GPU, KL once per forward, predictive mean; "
+                                   "bf16 operands / fp32 accumulate" if args.dtype == "bf16" else
+                                   "784-1200-1200-10 NormalLinear MLP, batch 512, 8 MC samples per forward per GPU, "
+                                   "exact fp32 MFMA (parity mode)",
+                       "samples_per_step_per_gpu": SAMPLES, "batch": BATCH,
+                       "hip_graph": not args.no_graph, "collective": "allreduce 5127 x fp32" if world > 1 else None},
+        }
+        if "f32" in results and args.dtype != "f32":
+            line["f32"] = {"value": round(results["f32"][0], 1), "ms_per_step": round(results["f32"][1], 4),
+                           "note": "same step, exact fp32 MFMA (the 1e-5 parity mode)"}
+        line["roofline"] = kernel_roofline(net, x, args.dtype, dev)
+        line["roofline_sampler"] = sampler_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(post, x_cpu)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -268,7 +268,10 @@ def test_linear_fused_philox_vs_oracle(env, shape, bias):
     y = layer(x)
     assert env["lib"].bnn_launch_count() == n0 + 1          # ONE fused launch
     w, b = _oracle_layer_draw(env["orc"], layer, 0)
-    assert allclose(N(y), env["orc"].linear(N(x), w, b))
+    # outputs of the K >= 784 shapes have rms 3-5: 1e-5 of the output scale (allclose_scaled);
+    # unit-scale shapes use the plain 1e-5 bar.
+    want = env["orc"].linear(N(x), w, b)
+    assert allclose_scaled(N(y), want) if K >= 784 else allclose(N(y), want)
     ws, bs = layer.sampled
     assert allclose(N(ws), w)
     if bias:

@@ -154,3 +154,23 @@ def test_north_star_mlp_two_samples():
     assert abs(orc.kl_divergence(tensors) - float(g["kl"])) <= 1e-5 * (1 + float(g["kl"]))
     for (mu, rho, pm, ps), want in zip(tensors, g["kl_parts"]):
         assert abs(orc.kl_sum(mu, rho, pm, ps) / mu.size - want) <= 1e-5 * (1 + abs(want))
+
+
+def test_reference_port_is_bit_identical_to_the_reference():
+    """oracle/reference_port.py (bench.py's cpu_baseline) == the reference, same seed."""
+    from oracle import reference_port as port
+    g = load_golden("mlp_784_1200_1200_10")
+    post = seeded.mlp_posteriors((784, 1200, 1200, 10), seed=int(g["param_seed"]))
+    x = seeded.mlp_input(512, 784, seed=int(g["x_seed"]))
+    torch.set_num_threads(1)
+    torch.manual_seed(int(g["eps_seed"]))
+    with torch.no_grad():
+        ys = port.mlp_forward(x, post, 2)
+        kl = port.kl_divergence_loss(post)
+    assert allclose_scaled(ys[0].numpy(), g["y0"]) and allclose_scaled(ys[1].numpy(), g["y1"])
+    assert abs(kl.item() - float(g["kl"])) < 1e-7
+    gl = load_golden("linear_7x11")
+    torch.manual_seed(int(gl["eps_seed"]))
+    y = port.normal_linear(torch.from_numpy(gl["x"]), torch.from_numpy(gl["mu_w"]), torch.from_numpy(gl["rho_w"]),
+                           torch.from_numpy(gl["mu_b"]), torch.from_numpy(gl["rho_b"]))
+    assert np.array_equal(y.numpy(), gl["y"])
