@@ -109,17 +109,17 @@ __device__ __forceinline__ float eps1(const RngDev &r, uint32_t epoch_dev, uint6
     return j == 0 ? z.x : j == 1 ? z.y : j == 2 ? z.z : z.w;
 }
 
-// sigma = 1e-10 + softplus(rho), torch semantics (beta 1, threshold 20).
-// log1p(e) = log(u) * e / (u - 1), u = 1 + e  (exact-rounding trick; = e when u == 1),
-// on the native exp2/log2 units: absolute error < 1e-7 * sigma + 1e-16, far inside 1e-5.
-__device__ __forceinline__ float sigma_fast(float rho)
+// sigma = 1e-10 + softplus(rho), torch semantics (beta 1, threshold 20), for the DRAW:
+// ln(1 + e^rho) on the raw exp2 / log2 units (v_exp_f32, v_log_f32; 8 instructions).
+// Absolute error <= ~1e-7 (the rounding of 1 + e), i.e. <= 1e-7 * |eps| on a drawn weight --
+// far inside the 1e-5 parity bar.  Every kernel that draws (K1, K2 loaders, backward)
+// uses THIS function, so a draw re-created from its key is bit-identical everywhere.
+// (KL takes ln(sigma) and therefore uses sigma_accurate below.)
+__device__ __forceinline__ float sigma_draw(float rho)
 {
-    const float e = __expf(rho);
-    const float u = 1.0f + e;
-    const float d = u - 1.0f;
-    float sp = (d == 0.0f) ? e : __logf(u) * __fdividef(e, d);
-    sp = rho > 20.0f ? rho : sp;
-    return 1e-10f + sp;
+    const float e = __builtin_amdgcn_exp2f(rho * 1.44269504088896341f);
+    const float sp = __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f;
+    return 1e-10f + (rho > 20.0f ? rho : sp);
 }
 
 // Same value through the accurate ocml routines (used where ln(sigma) is taken: KL).

@@ -79,17 +79,17 @@ __global__ __launch_bounds__(kThreads) void k_sample_affine_eps(
             const float4 r = reinterpret_cast<const float4 *>(rho)[v];
             const float4 e = reinterpret_cast<const float4 *>(eps)[v];
             float4 w;
-            w.x = fmaf(sigma_fast(r.x), e.x, m.x);
-            w.y = fmaf(sigma_fast(r.y), e.y, m.y);
-            w.z = fmaf(sigma_fast(r.z), e.z, m.z);
-            w.w = fmaf(sigma_fast(r.w), e.w, m.w);
+            w.x = fmaf(sigma_draw(r.x), e.x, m.x);
+            w.y = fmaf(sigma_draw(r.y), e.y, m.y);
+            w.z = fmaf(sigma_draw(r.z), e.z, m.z);
+            w.w = fmaf(sigma_draw(r.w), e.w, m.w);
             store4<DT>(out, v, w);
         }
         for (int64_t i = (nvec << 2) + tid; i < n; i += nthreads)
-            store1<DT>(out, i, fmaf(sigma_fast(rho[i]), eps[i], mu[i]));
+            store1<DT>(out, i, fmaf(sigma_draw(rho[i]), eps[i], mu[i]));
     } else {
         for (int64_t i = tid; i < n; i += nthreads)
-            store1<DT>(out, i, fmaf(sigma_fast(rho[i]), eps[i], mu[i]));
+            store1<DT>(out, i, fmaf(sigma_draw(rho[i]), eps[i], mu[i]));
     }
 }
 
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(kThreads) void k_sample_affine_philox(
                 m.z = base + 2 < n ? mu[base + 2] : 0.f; r.z = base + 2 < n ? rho[base + 2] : 0.f;
                 m.w = base + 3 < n ? mu[base + 3] : 0.f; r.w = base + 3 < n ? rho[base + 3] : 0.f;
             }
-            sg.x = sigma_fast(r.x); sg.y = sigma_fast(r.y);
-            sg.z = sigma_fast(r.z); sg.w = sigma_fast(r.w);
+            sg.x = sigma_draw(r.x); sg.y = sigma_draw(r.y);
+            sg.z = sigma_draw(r.z); sg.w = sigma_draw(r.w);
         }
         for (int s = 0; s < nsamples; ++s) {
             const float4 z = eps4(rng, edev, (uint32_t)v, rng.sample0 + (uint32_t)s);
@@ -212,6 +212,37 @@ __global__ __launch_bounds__(kThreads) void k_mc_sum(const float *__restrict__ y
         a *= scale;
         out[i] = accumulate ? out[i] + a : a;
     }
+}
+
+// ---------------------------------------------------------------- diagnostics
+// VALU cost of the draw: every thread runs `iters` Philox blocks (4 draws each) of the chosen
+// stage and keeps one live value; nothing but one store per thread touches memory.
+// stage 0: Philox only; 1: + Box-Muller; 2: + sigma_fast per element; 3: + fma (full draw).
+template <int STAGE>
+__global__ __launch_bounds__(kThreads) void k_diag_sampler(float *__restrict__ out, int iters, RngDev rng)
+{
+    const uint32_t tid = blockIdx.x * kThreads + threadIdx.x;
+    float acc = 0.f;
+    float rho = -2.0f + 1e-6f * (float)(tid & 1023);
+    for (int i = 0; i < iters; ++i) {
+        const uint32_t blk = tid * (uint32_t)iters + (uint32_t)i;
+        if constexpr (STAGE == 0) {
+            const uint4 x = philox4x32_10(make_uint4(blk, rng.stream_hi, rng.epoch_host, 0u), rng.key0, rng.key1);
+            acc += __uint_as_float((x.x ^ x.y ^ x.z ^ x.w) & 0x3F800000u);
+        } else {
+            const float4 z = eps4(rng, 0u, blk, 0u);
+            if constexpr (STAGE == 1) {
+                acc += z.x + z.y + z.z + z.w;
+            } else {
+                const float s0 = sigma_draw(rho), s1 = sigma_draw(rho + 0.25f), s2 = sigma_draw(rho + 0.5f),
+                            s3 = sigma_draw(rho + 0.75f);
+                rho += 1e-7f;
+                if constexpr (STAGE == 2) acc += z.x + z.y + z.z + z.w + s0 + s1 + s2 + s3;
+                else acc += fmaf(s0, z.x, 0.1f) + fmaf(s1, z.y, 0.2f) + fmaf(s2, z.z, 0.3f) + fmaf(s3, z.w, 0.4f);
+            }
+        }
+    }
+    out[tid] = acc;
 }
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -326,6 +357,22 @@ int bnn_rng_advance(uint32_t *epoch_dev, uint32_t inc, void *stream)
     if (!epoch_dev) { set_error("bnn_rng_advance: NULL pointer"); return BNN_E_NULL; }
     hipLaunchKernelGGL(k_rng_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, epoch_dev, inc);
     return check_launch("bnn_rng_advance");
+}
+
+int bnn_diag_sampler(float *out, int blocks, int iters, int stage, void *stream)
+{
+    if (!out) { set_error("bnn_diag_sampler: NULL pointer"); return BNN_E_NULL; }
+    if (blocks < 1 || iters < 1 || stage < 0 || stage > 3) { set_error("bnn_diag_sampler: bad argument"); return BNN_E_SHAPE; }
+    bnn_rng_t r{}; r.seed = 0x9E3779B97F4A7C15ull; r.stream = 1;
+    const RngDev rd = make_rng(&r);
+    hipStream_t st = (hipStream_t)stream;
+    switch (stage) {
+    case 0: hipLaunchKernelGGL(k_diag_sampler<0>, dim3(blocks), dim3(kThreads), 0, st, out, iters, rd); break;
+    case 1: hipLaunchKernelGGL(k_diag_sampler<1>, dim3(blocks), dim3(kThreads), 0, st, out, iters, rd); break;
+    case 2: hipLaunchKernelGGL(k_diag_sampler<2>, dim3(blocks), dim3(kThreads), 0, st, out, iters, rd); break;
+    default: hipLaunchKernelGGL(k_diag_sampler<3>, dim3(blocks), dim3(kThreads), 0, st, out, iters, rd); break;
+    }
+    return check_launch("bnn_diag_sampler");
 }
 
 int bnn_mc_sum(const float *y, int64_t y_sample_stride, int nsamples, int64_t n, float scale,

@@ -18,46 +18,15 @@
 //   * all MC samples of a layer run in ONE grid (sample = part of the block index), and
 //     the block index is decoded XCD-aware: workgroups that share a (mu, rho) column
 //     panel have equal blockIdx % 8, i.e. share one XCD's L2.
+#include <cstdlib>
+
 #include "bnn_device.hpp"
+#include "bnn_gemm_params.hpp"
 
 namespace bnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-enum { A_DENSE = 0, A_IM2COL = 1 };
-enum { B_PLAIN = 0, B_SAMPLED = 1 };
-
-struct GemmParams {
-    // A operand
-    const float *A;
-    int64_t a_sample_stride;
-    int64_t lda;
-    // im2col geometry (A_IM2COL)
-    int32_t C, H, W, OH, OW, KH, KW, sh, sw, ph, pw, dh, dw, Cg;
-    // B operand
-    const float *Bw;            // plain weights (N_total, K)
-    int64_t b_sample_stride;
-    const float *mu;            // sampled weights
-    const float *rho;
-    // bias: plain (bias) or sampled (mu_b, rho_b)
-    const float *bias;
-    int64_t bias_sample_stride;
-    const float *mu_b;
-    const float *rho_b;
-    // output
-    float *Y;
-    int64_t y_sample_stride;
-    int64_t ldy;
-    int32_t O;                  // conv: total output channels
-    // extents: per group M x N x K
-    int32_t M, N, K;
-    int32_t S, G;
-    int32_t ntn, ntm;           // tiles
-    int32_t flags;
-    int32_t vecA, vecB;         // 16-B loads legal
-    RngDev rng_w, rng_b;
-};
 
 __device__ __forceinline__ int swz(int row, int chunk)
 {
@@ -215,16 +184,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const GemmParams p)
 #pragma unroll
                     for (int v = 0; v < KPC / 4; ++v) {
                         const float4 z = eps4(p.rng_w, edev_w, (uint32_t)((e0 >> 2) + v), sample);
-                        bm[i][4 * v] = fmaf(sigma_fast(br[i][4 * v]), z.x, bm[i][4 * v]);
-                        bm[i][4 * v + 1] = fmaf(sigma_fast(br[i][4 * v + 1]), z.y, bm[i][4 * v + 1]);
-                        bm[i][4 * v + 2] = fmaf(sigma_fast(br[i][4 * v + 2]), z.z, bm[i][4 * v + 2]);
-                        bm[i][4 * v + 3] = fmaf(sigma_fast(br[i][4 * v + 3]), z.w, bm[i][4 * v + 3]);
+                        bm[i][4 * v] = fmaf(sigma_draw(br[i][4 * v]), z.x, bm[i][4 * v]);
+                        bm[i][4 * v + 1] = fmaf(sigma_draw(br[i][4 * v + 1]), z.y, bm[i][4 * v + 1]);
+                        bm[i][4 * v + 2] = fmaf(sigma_draw(br[i][4 * v + 2]), z.z, bm[i][4 * v + 2]);
+                        bm[i][4 * v + 3] = fmaf(sigma_draw(br[i][4 * v + 3]), z.w, bm[i][4 * v + 3]);
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < KPC; ++j)
                         if (kb + j < p.K)
-                            bm[i][j] = fmaf(sigma_fast(br[i][j]), eps1(p.rng_w, edev_w, (uint64_t)(e0 + j), sample), bm[i][j]);
+                            bm[i][j] = fmaf(sigma_draw(br[i][j]), eps1(p.rng_w, edev_w, (uint64_t)(e0 + j), sample), bm[i][j]);
                 }
             }
         }
@@ -335,7 +304,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_gemm_nt(const GemmParams p)
         const int64_t ng = nrow0 + n;
         float bias = 0.f;
         if (sampled_bias)
-            bias = fmaf(sigma_fast(p.rho_b[ng]), eps1(p.rng_b, edev_b, (uint64_t)ng, p.rng_b.sample0 + (uint32_t)s), p.mu_b[ng]);
+            bias = fmaf(sigma_draw(p.rho_b[ng]), eps1(p.rng_b, edev_b, (uint64_t)ng, p.rng_b.sample0 + (uint32_t)s), p.mu_b[ng]);
         else if (p.bias)
             bias = p.bias[(int64_t)s * p.bias_sample_stride + ng];
 #pragma unroll
@@ -434,6 +403,10 @@ static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
     p.vecA = al16(x) && (ldx % 4 == 0) && (x_sample_stride % 4 == 0);
     p.vecB = (K % 4 == 0) && (sampled ? (al16(mu_w) && al16(rho_w)) : (al16(w) && w_sample_stride % 4 == 0));
     if (sampled) { p.rng_w = make_rng(rng_w); p.rng_b = make_rng(mu_b ? rng_b : nullptr); }
+    // sampler-paced kernel (bnn_linear.hip) whenever 16-B loads are legal; BNN_LINEAR_KERNEL=v1
+    // forces the generic tile kernel (A/B comparisons).
+    static const bool force_v1 = [] { const char *e = getenv("BNN_LINEAR_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+    if (p.vecA && p.vecB && !force_v1) return dispatch_linear_v2(p, sampled, compute, (hipStream_t)stream, who);
     return dispatch<A_DENSE>(p, sampled, compute, (hipStream_t)stream, who);
 }
 

@@ -1,0 +1,43 @@
+// bnn_gemm_params.hpp -- kernel-argument block shared by the contraction kernels.
+#pragma once
+#include "bnn_device.hpp"
+
+namespace bnn {
+
+enum { A_DENSE = 0, A_IM2COL = 1 };
+enum { B_PLAIN = 0, B_SAMPLED = 1 };
+
+struct GemmParams {
+    // A operand
+    const float *A;
+    int64_t a_sample_stride;
+    int64_t lda;
+    // im2col geometry (A_IM2COL)
+    int32_t C, H, W, OH, OW, KH, KW, sh, sw, ph, pw, dh, dw, Cg;
+    // B operand
+    const float *Bw;            // plain weights (N_total, K)
+    int64_t b_sample_stride;
+    const float *mu;            // sampled weights
+    const float *rho;
+    // bias: plain (bias) or sampled (mu_b, rho_b)
+    const float *bias;
+    int64_t bias_sample_stride;
+    const float *mu_b;
+    const float *rho_b;
+    // output
+    float *Y;
+    int64_t y_sample_stride;
+    int64_t ldy;
+    int32_t O;                  // conv: total output channels
+    // extents: per group M x N x K
+    int32_t M, N, K;
+    int32_t S, G;
+    int32_t ntn, ntm;           // tiles
+    int32_t flags;
+    int32_t vecA, vecB;         // 16-B loads legal
+    RngDev rng_w, rng_b;
+};
+
+int dispatch_linear_v2(GemmParams &p, bool sampled, int compute, hipStream_t st, const char *who);
+
+}  // namespace bnn

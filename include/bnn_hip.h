@@ -189,6 +189,12 @@ int bnn_conv2d_forward(const float *x, int64_t x_sample_stride,
                        const bnn_conv2d_shape_t *shape, int nsamples,
                        int compute, int flags, void *stream);
 
+/* ---- diagnostics ------------------------------------------------------------
+ * VALU cost of the draw, no memory traffic: `blocks` workgroups of 256 threads each run
+ * `iters` Philox blocks (4 draws) of stage 0 (Philox4x32-10 only), 1 (+ Box-Muller),
+ * 2 (+ softplus sigma), 3 (+ fma = full draw); out needs blocks * 256 floats. */
+int bnn_diag_sampler(float *out, int blocks, int iters, int stage, void *stream);
+
 /* ---- MC reduction ----------------------------------------------------------
  * replaces  torch.stack(preds).mean(0)   examples/MNIST/uncertainty.py:50
  *   out[i] (+)= scale * sum_s y[s * y_sample_stride + i],  i < n. */
