@@ -77,6 +77,7 @@ SIGNATURES = {
     "bnn_conv2d_forward": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape),
                                   _int, _int, _int, _p]),
     "bnn_diag_sampler": (_int, [_p, _int, _int, _int, _p]),
+    "bnn_diag_astream": (_int, [_p, _int, _int, _int, _int, _int, _int, _int, _p, _p]),
     "bnn_mc_sum": (_int, [_p, _i64, _int, _i64, _f, _p, _int, _p]),
 }
 

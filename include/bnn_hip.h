@@ -194,6 +194,12 @@ int bnn_conv2d_forward(const float *x, int64_t x_sample_stride,
  * `iters` Philox blocks (4 draws) of stage 0 (Philox4x32-10 only), 1 (+ Box-Muller),
  * 2 (+ softplus sigma), 3 (+ fma = full draw); out needs blocks * 256 floats. */
 int bnn_diag_sampler(float *out, int blocks, int iters, int stage, void *stream);
+/* L2 -> CU activation stream in the access shapes of the fused linear kernel: S * (M / rows_per_wg)
+ * * ntn workgroups of nwaves waves each read their (rows_per_wg x K) block of x (S, M, K) once.
+ * pattern 0: MFMA-fragment shaped loads; 1: row-contiguous loads; 2: row-contiguous LDS-DMA.
+ * out needs grid * nwaves * 64 floats. */
+int bnn_diag_astream(const float *x, int S, int M, int K, int rows_per_wg, int ntn, int pattern,
+                     int nwaves, float *out, void *stream);
 
 /* ---- MC reduction ----------------------------------------------------------
  * replaces  torch.stack(preds).mean(0)   examples/MNIST/uncertainty.py:50
