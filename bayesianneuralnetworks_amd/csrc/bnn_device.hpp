@@ -142,9 +142,14 @@ __device__ __forceinline__ uint16_t f2bf(float v)
     return __builtin_bit_cast(uint16_t, h);
 }
 
+// two fp32 -> packed bf16x2 (lo in bits 15:0): one v_cvt_pk_bf16_f32 (RNE, NaN kept NaN)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 template <typename T>

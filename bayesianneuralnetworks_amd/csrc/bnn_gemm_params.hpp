@@ -36,6 +36,8 @@ struct GemmParams {
     int32_t flags;
     int32_t vecA, vecB;         // 16-B loads legal
     RngDev rng_w, rng_b;
+    unsigned long long *dbg;    // diagnostic stamps (bnn_linear.hip, STAMPS build), normally NULL
+    int32_t dbg_block;
 };
 
 int dispatch_linear_v2(GemmParams &p, bool sampled, int compute, hipStream_t st, const char *who);

@@ -1,26 +1,31 @@
-// bnn_linear.hip -- K2-linear, the draw-paced fused kernel (dense A, 16-B aligned operands).
+// bnn_linear.hip -- K2-linear: the fused sampled GEMM as a producer / consumer pipeline
+// (dense A, 16-B aligned operands, K % 4 == 0).
 //
-//   y[s] = x[s] . W_s^T + b_s,   W_s = mu + sigma(rho) * eps_s   drawn in the B-operand loader.
+//   y[s] = x[s] . W_s^T + b_s,   W_s = mu + sigma(rho) * eps_s   drawn on the fly, never stored.
 //
-// Why a second kernel next to bnn_gemm.hip: at the BASELINE shapes the scarce resources are the
-// eps draw (VALU: ~2.4 SIMD-cycles per draw, bnn_diag_sampler) and the activation stream through
-// each CU's vector L1 -- not the MFMA (8 x 1.44 M draws but only 11.8 GFLOP of bf16 MFMA in the
-// layer-2 launch).  Hence:
-//   * one workgroup owns ALL batch rows of one MC sample for a column panel (BM = 512 in bf16
-//     mode), so each weight of a sample is drawn exactly once;
-//   * waves split the tile along M only: an activation row is consumed by exactly one wave,
-//     so A never touches LDS -- every lane loads its own MFMA fragment (8 consecutive k) straight
-//     from global memory / L2 into registers, one step ahead, with no barrier in its path;
-//   * only the drawn weights go through LDS (12-20 KB, double-buffered, one barrier per step);
-//     every wave draws an equal share of the Philox blocks of a step;
-//   * block decode puts MC sample s on XCD s % 8: the sample's activations (2.4 MB at the
-//     BASELINE shape) stay in that XCD's 4 MB L2 while mu / rho stream through.
+// What the measurements on MI355X said (tools/diag_*.py, profiles/):
+//   * the eps draw costs ~2.4 SIMD-cycles per weight and is a ~600-instruction dependent chain
+//     (Philox rounds -> Box-Muller -> softplus): put in series with the MFMAs of a k-step it
+//     dominated every step;
+//   * fragment-shaped or row-shaped global loads into VGPRs pull only 7-15 B/clk per CU out of
+//     L2, LDS-DMA (global_load_lds_dwordx4) 40-50 B/clk;
+//   * a workgroup barrier per k-step left every wave parked 60 % of the time (SQ_WAIT_ANY).
+// Hence this structure, with NO workgroup barrier in the main loop:
+//   consumer waves (NC): each owns 32 batch rows.  It LDS-DMAs ITS OWN rows of x into a private
+//     3-stage LDS ring (8 lanes fetch one 128-B line, swizzled on the source address), waits with
+//     a counted vmcnt for its own pieces only, reads A / B fragments with ds_read_b128 and issues
+//     the MFMAs (v_mfma_f32_16x16x32_bf16, or 8 x v_mfma_f32_16x16x4_f32 for exact fp32).
+//   producer waves (NP): fetch (mu, rho) one chunk ahead (inline-asm loads + counted vmcnt, so
+//     hipcc cannot drain them), draw CH k-steps worth of weights at a time -- several independent
+//     Philox blocks per lane in flight -- and write them to a double-buffered LDS chunk.
+//   hand-off: per chunk buffer a FULL counter (producers add after their ds_writes completed)
+//     and a FREE counter (consumers add after their last read), both plain LDS words polled with
+//     ds_read + s_sleep.  All LDS lives in one __shared__ array.
+//   block decode puts MC sample s on XCD s % 8: a sample's activations stay in that XCD's L2.
 //
-// k order inside a 32-wide macro-step: MFMA lane (i = l & 15, q = l >> 4) holds k = 4q + t
-// (t = 0..3) and k = 16 + 4q + (t - 4) (t = 4..7) -- two 64-B-contiguous global loads per row;
-// the same permutation is applied to B when its 4-draw units are written to LDS, so the sum is
-// unchanged.  bf16: one v_mfma_f32_16x16x32_bf16 per macro-step; fp32: eight
-// v_mfma_f32_16x16x4_f32 (MFMA k-slot q, step t).
+// k order inside a 32-wide step: MFMA lane (i = l & 15, q = l >> 4) holds k = 4q + t (t < 4) and
+// k = 16 + 4q + (t - 4) (t >= 4); B's 4-draw unit c (k = 4c..4c+3) is written for lane-q c & 3,
+// half c >> 2 -- the same permutation on both operands leaves the sum unchanged.
 #include <cstdlib>
 
 #include "bnn_device.hpp"
@@ -31,7 +36,7 @@ namespace bnn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// LDS position of 16-B chunk `c` of B row `row`.
+// LDS position (in 16-B chunks) of chunk `c` of B row `row` inside one 32-k sub-tile.
 // bf16: [row][4 chunks], swizzle h((row >> 2) & 3), h = {0, 2, 3, 1};
 // fp32: [row][8 chunks], swizzle row & 7.  Both conflict-free for ds_read_b128.
 template <bool F32>
@@ -41,34 +46,110 @@ __device__ __forceinline__ int bpos(int row, int c)
     else return row * 4 + (c ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3));
 }
 
-// One LDS-DMA piece: 64 lanes x 16 B land at lds_dst + 16 * lane (lds_dst wave-uniform);
-// every lane supplies its own global source address.
-__device__ __forceinline__ void dma16(const float *src, void *lds_dst)
+// One LDS-DMA piece: 64 lanes x 16 B land at LDS byte address lds_addr + 16 * lane (lds_addr
+// wave-uniform, in an SGPR -> M0); every lane supplies its own global source address.
+// Inline asm ON PURPOSE: with __builtin_amdgcn_global_load_lds hipcc knows that LDS is written
+// asynchronously and puts s_waitcnt vmcnt(0) in front of every ds_read of the kernel (measured:
+// the DMA ring drained every k-step).  Here the counted s_waitcnt vmcnt(N) below is the only
+// wait.  M0 is saved / restored inside the statement (it is compiler-reserved).
+__device__ __forceinline__ void dma16(const float *src, uint32_t lds_addr)
 {
-    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_addr)
+                 : "memory");
+}
+// PW pieces with ONE M0 write: the instruction offset is added to BOTH the LDS address and the
+// global address, so piece j uses offset 1024 * j and a source pointer moved back by 1024 * j bytes.
+template <int PW>
+__device__ __forceinline__ void dma16xN(const float *const (&src)[PW], int kofs, uint32_t lds_addr)
+{
+    uint32_t keep;
+    if constexpr (PW == 1) {
+        const float *p0 = src[0] + kofs;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(p0), "s"(lds_addr) : "memory");
+    } else if constexpr (PW == 2) {
+        const float *p0 = src[0] + kofs, *p1 = src[1] + kofs - 256;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(p0), "v"(p1), "s"(lds_addr) : "memory");
+    } else {
+        static_assert(PW == 4, "PW");
+        const float *p0 = src[0] + kofs, *p1 = src[1] + kofs - 256, *p2 = src[2] + kofs - 512, *p3 = src[3] + kofs - 768;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(lds_addr) : "memory");
+    }
 }
 
-template <int BM, int BN, int B_MODE, int COMPUTE>
-__global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
-    constexpr int NT = 512, NW = 8;
-    constexpr bool F32 = (COMPUTE == BNN_COMPUTE_F32);
-    constexpr int BK = 32;
-    constexpr int WTM = BM / NW;
-    constexpr int TM = WTM / 16, TN = BN / 16;
-    static_assert(WTM % 16 == 0 && BN % 16 == 0, "tile");
-    constexpr int A_TILE = BM * 8;              // uint4 per A buffer: [BM rows][8 chunks of 4 fp32]
-    constexpr int A_PIECES = BM / 8;            // 1-KiB LDS-DMA pieces (8 rows x 128 B) per tile
-    constexpr int A_PPW = A_PIECES / NW;        // pieces per wave
-    constexpr int CPR = F32 ? 8 : 4;            // 16-B chunks per B row
-    constexpr int B_TILE = BN * CPR;
-    constexpr int UPR = 8;                      // 4-draw units per B row per step
-    constexpr int B_UNITS = BN * UPR;
-    constexpr int B_PER = (B_UNITS + NT - 1) / NT;
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
 
-    constexpr int NA_STAGES = 3;
-    __shared__ __attribute__((aligned(16))) uint4 lds[NA_STAGES * A_TILE + 2 * B_TILE];
-    uint4 *As0 = lds, *Bs0 = lds + NA_STAGES * A_TILE;
+__device__ __forceinline__ int lds_load(int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Poll an LDS counter until it reaches `target` (bounded: a protocol bug must not hang the GPU).
+__device__ __forceinline__ void lds_wait_ge(int *p, int target)
+{
+    for (int spin = 0; spin < (1 << 24); ++spin) {
+        if (lds_load(p) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Symmetric pipeline: every wave draws its share of chunk ch+1, then consumes chunk ch for its own
+// RW rows.  NW waves (16 -> 4 per SIMD: the draw saturates the VALU while other waves sit in DMA /
+// MFMA), BM = NW * RW rows per workgroup, BN columns, CH k-steps (32 k each) per chunk, S-stage
+// private A ring per wave.
+// STAMPS: diagnostic build only (BNN_STAMPS=<device pointer>): wave 0 of block p.dbg_block writes
+// s_memtime stamps to p.dbg; stamps never feed an output value.
+template <int NW, int RW, int BN, int CH, int S, int NB, int B_MODE, int COMPUTE, bool STAMPS = false>
+__global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
+{
+    constexpr bool F32 = (COMPUTE == BNN_COMPUTE_F32);
+    constexpr int NT = NW * 64;
+    constexpr int BM = NW * RW;
+    constexpr int TM = RW / 16, TN = BN / 16;
+    static_assert(RW % 16 == 0 && BN % 16 == 0, "tile");
+    constexpr int PW = RW / 8;                  // 1-KiB DMA pieces per wave per k-step
+    constexpr int A_STAGE = RW * 8;             // uint4 per wave per stage: RW rows x 8 chunks
+    constexpr int CPR = F32 ? 8 : 4;            // 16-B chunks per B row per 32-k sub-tile
+    constexpr int B_SUB = BN * CPR;             // uint4 per sub-tile
+    constexpr int B_CHUNK = CH * B_SUB;         // uint4 per chunk buffer
+    constexpr int UPC = BN * 8 * CH;            // 4-draw units per chunk
+    static_assert(UPC <= NT, "one unit per lane per chunk");
+    constexpr int LPU = (B_MODE == B_SAMPLED ? 2 : 1);   // raw loads per unit
+    constexpr int A_WORDS = NW * S * A_STAGE;
+    constexpr int WAIT_DRAW = (CH < S - 1 ? CH : S - 1) * PW + LPU;
+    constexpr int LA = NB > 2 ? NB - 2 : 1;     // chunks drawn ahead of the one being consumed
+
+    // NB chunk buffers: chunk c lives in buffer c % NB; with NB > 2 a wave may draw up to NB - 1
+    // chunks ahead of the slowest consumer instead of meeting it at every chunk.
+    __shared__ __attribute__((aligned(16))) uint4 lds[A_WORDS + NB * B_CHUNK + (2 * NB + 3) / 4];
+    uint4 *Bs0 = lds + A_WORDS;
+    int *full = reinterpret_cast<int *>(lds + A_WORDS + NB * B_CHUNK);   // full[NB], then free[NB]
+    int *freec = full + NB;
+
+    unsigned long long *dbg = nullptr;
+    int dbg_i = 0;
+    auto stamp = [&](int tag) {
+        if constexpr (STAMPS) {
+            if (dbg && dbg_i < 2000) {
+                unsigned long long t;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+                if ((threadIdx.x & 63) == 0) { dbg[2 * dbg_i] = (unsigned long long)tag; dbg[2 * dbg_i + 1] = t; }
+                ++dbg_i;
+            }
+        }
+    };
 
     // ---- block decode
     const int L = blockIdx.x;
@@ -77,8 +158,7 @@ __global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
         const int per_s = p.ntn * p.ntm;
         int rem;
         if (p.S % 8 == 0) {
-            // MC sample -> XCD: blocks with equal blockIdx % 8 share one XCD's L2
-            const int i_in = L >> 3;
+            const int i_in = L >> 3;            // MC sample -> XCD (blockIdx % 8)
             s = (L & 7) + 8 * (i_in / per_s);
             rem = i_in % per_s;
         } else {
@@ -89,118 +169,97 @@ __global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
         mt = rem % p.ntm;
     }
     const int m0 = mt * BM, n0 = panel * BN;
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, fq = lane >> 4;
+    const int kmax = p.K - 4;
+    const int nk = (p.K + 31) / 32;             // 32-wide k-steps
+    const int nch = (nk + CH - 1) / CH;         // chunks (steps past nk multiply exact zeros)
+
+    if (tid < 2 * NB) full[tid] = 0;
+    __syncthreads();
+    if constexpr (STAMPS) {
+        if (p.dbg && (int)blockIdx.x == p.dbg_block && wave == 0) dbg = p.dbg;
+    }
+
+    // ---- draw side: this lane's unit of every chunk
     const uint32_t sample = p.rng_w.sample0 + (uint32_t)s;
     uint32_t edev_w = 0;
     if constexpr (B_MODE == B_SAMPLED) edev_w = rng_epoch_dev(p.rng_w);
-    const float *Ab = p.A + (int64_t)s * p.a_sample_stride;
     const float *Bsrc = (B_MODE == B_SAMPLED) ? p.mu : p.Bw + (int64_t)s * p.b_sample_stride;
-    const int kmax = p.K - 4;
+    const bool draws = tid < UPC;
+    const int u_row = (tid / (8 * CH)) % BN, u_cc = tid % (8 * CH);    // cc = sub * 8 + c
+    int64_t brow;
+    {
+        int n = n0 + u_row;
+        n = n < p.N ? n : p.N - 1;              // columns >= N: clamped loads, results never stored
+        brow = (int64_t)n * p.K;
+    }
+    f32x4 rmA, rrA, rmB, rrB;                   // raw (mu, rho) of chunk ch+1 / ch+2
+    rrA = rrB = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch_unit = [&](f32x4 &m, f32x4 &r, int ch) {
+        int kb = ch * (32 * CH) + 4 * u_cc;
+        kb = kb < kmax ? kb : kmax;             // past K: clamped, drawn as zeros
+        const float *pm = Bsrc + brow + kb;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(m) : "v"(pm) : "memory");
+        if constexpr (B_MODE == B_SAMPLED) {
+            const float *pr = p.rho + brow + kb;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(pr) : "memory");
+        }
+    };
+    auto draw_unit = [&](const f32x4 &m, const f32x4 &r, int ch) {
+        if (!draws) return;
+        char *buf = reinterpret_cast<char *>(Bs0 + (ch % NB) * B_CHUNK);
+        const int sub = u_cc >> 3, c = u_cc & 7;
+        const int n = n0 + u_row;
+        const int kb = ch * (32 * CH) + 4 * u_cc;
+        float4 w = make_float4(m[0], m[1], m[2], m[3]);
+        if constexpr (B_MODE == B_SAMPLED) {
+            // element index from the UNclamped (n, k): columns >= N draw values nobody reads
+            const int64_t e0 = (int64_t)n * p.K + kb;
+            const float4 z = eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
+            w.x = fmaf(sigma_draw(r[0]), z.x, w.x);
+            w.y = fmaf(sigma_draw(r[1]), z.y, w.y);
+            w.z = fmaf(sigma_draw(r[2]), z.z, w.z);
+            w.w = fmaf(sigma_draw(r[3]), z.w, w.w);
+        }
+        if (kb >= p.K) w = make_float4(0.f, 0.f, 0.f, 0.f);           // K tail: exact zeros
+        char *tile = buf + sub * (B_SUB * 16);
+        if constexpr (F32) {
+            uint4 o;
+            o.x = __float_as_uint(w.x); o.y = __float_as_uint(w.y);
+            o.z = __float_as_uint(w.z); o.w = __float_as_uint(w.w);
+            *reinterpret_cast<uint4 *>(tile + bpos<true>(u_row, c) * 16) = o;
+        } else {
+            uint2 o;
+            o.x = pack_bf16x2(w.x, w.y);
+            o.y = pack_bf16x2(w.z, w.w);
+            *reinterpret_cast<uint2 *>(tile + bpos<false>(u_row, c & 3) * 16 + (c >> 2) * 8) = o;
+        }
+    };
+    auto publish = [&](int ch) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // this wave's ds_writes are done
+        if (lane == 0) __hip_atomic_fetch_add(&full[ch % NB], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
-    // ---- A: LDS-DMA.  Piece pc = rows 8*pc .. 8*pc+7 of the tile; lane l lands at LDS chunk
-    // position l & 7 of row l >> 3, so it must FETCH global chunk (l & 7) ^ (row & 7)
-    // (the ds_read swizzle is applied on the source address; every 8 lanes read one full 128-B
-    // line).  Rows >= M are clamped (outputs never stored), k >= K is clamped to K-4 (B is 0 there).
-    const float *asrc[A_PPW];
+    // ---- consume side: this wave's RW rows
+    const float *Ab = p.A + (int64_t)s * p.a_sample_stride;
+    uint4 *Aw = lds + wave * (S * A_STAGE);             // this wave's private ring
+    const uint32_t aw_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(Aw));
+    // DMA piece j: rows 8j..8j+7 of this wave's RW; lane l lands at chunk position l & 7 of row
+    // 8j + (l >> 3), so it fetches global chunk (l & 7) ^ (row & 7) (swizzle on the source).
+    const float *asrc[PW];
 #pragma unroll
-    for (int j = 0; j < A_PPW; ++j) {
-        const int row = (wave + j * NW) * 8 + (lane >> 3);
-        int m = m0 + row;
-        m = m < p.M ? m : p.M - 1;
+    for (int j = 0; j < PW; ++j) {
+        int m = m0 + wave * RW + j * 8 + (lane >> 3);
+        m = m < p.M ? m : p.M - 1;                      // rows >= M: clamped, outputs never stored
         asrc[j] = Ab + (int64_t)m * p.lda;
     }
     const int a_chunk = (lane & 7) ^ ((lane >> 3) & 7);
-    auto dma_A = [&](int buf, int k0) {
-        int k = k0 + 4 * a_chunk;
-        k = k < kmax ? k : kmax;
-#pragma unroll
-        for (int j = 0; j < A_PPW; ++j) {
-            uint4 *dst = As0 + buf * A_TILE + (wave + j * NW) * 64;
-            dma16(asrc[j] + k, dst);
-        }
-    };
-
-    // ---- B: raw (mu, rho) units, two register sets (tile k+1 waiting to be drawn, tile k+2 in
-    // flight).  The loads are inline asm: hipcc does not see them, so it cannot drain the LDS-DMA
-    // pipeline with a vmcnt(0) when their results are used -- the counted waits below are ours.
-    f32x4 rmA[B_PER], rrA[B_PER], rmB[B_PER], rrB[B_PER];
-    int64_t brow[B_PER];
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-        const int u = tid + i * NT;
-        int n = n0 + (u / UPR) % BN;
-        n = n < p.N ? n : p.N - 1;
-        brow[i] = (int64_t)n * p.K;
-    }
-    constexpr int NB_OPS = B_PER * (B_MODE == B_SAMPLED ? 2 : 1);   // VMEM ops per load_B
-    constexpr int NA_OPS = A_PPW;                                   // VMEM ops per dma_A
-    auto load_B = [&](f32x4 (&rm)[B_PER], f32x4 (&rr)[B_PER], int k0) {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int u = tid + i * NT;
-            int kb = k0 + 4 * (u % UPR);
-            kb = kb < kmax ? kb : kmax;
-            const float *pm = Bsrc + brow[i] + kb;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rm[i]) : "v"(pm) : "memory");
-            if constexpr (B_MODE == B_SAMPLED) {
-                const float *pr = p.rho + brow[i] + kb;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rr[i]) : "v"(pr) : "memory");
-            }
-        }
-    };
-    // wait until all but the youngest N VMEM ops of this wave are done; the raw registers are
-    // operands so that no consumer of them is scheduled above the wait
-    auto wait_B = [&](f32x4 (&rm)[B_PER], f32x4 (&rr)[B_PER]) {
-        if constexpr (B_PER == 1) {
-            if constexpr (B_MODE == B_SAMPLED)
-                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rm[0]), "+v"(rr[0]) : "n"(NA_OPS + NB_OPS) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rm[0]) : "n"(NA_OPS + NB_OPS) : "memory");
-        } else {
-            static_assert(B_PER == 2, "B_PER");
-            if constexpr (B_MODE == B_SAMPLED)
-                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rm[0]), "+v"(rr[0]), "+v"(rm[1]), "+v"(rr[1]) : "n"(NA_OPS + NB_OPS) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rm[0]), "+v"(rm[1]) : "n"(NA_OPS + NB_OPS) : "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto draw_B = [&](const f32x4 (&rm)[B_PER], const f32x4 (&rr)[B_PER], int buf, int k0) {
-        char *tile = reinterpret_cast<char *>(Bs0 + buf * B_TILE);
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int u = tid + i * NT;
-            if (u >= B_UNITS) continue;
-            const int row = u / UPR, c = u % UPR;
-            const int n = n0 + row;
-            const int kb = k0 + 4 * c;
-            float4 w = make_float4(rm[i][0], rm[i][1], rm[i][2], rm[i][3]);
-            if constexpr (B_MODE == B_SAMPLED) {
-                // element index from the UNclamped (n, k): columns >= N draw garbage nobody reads
-                const int64_t e0 = (int64_t)n * p.K + kb;
-                const float4 z = eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
-                w.x = fmaf(sigma_draw(rr[i][0]), z.x, w.x);
-                w.y = fmaf(sigma_draw(rr[i][1]), z.y, w.y);
-                w.z = fmaf(sigma_draw(rr[i][2]), z.z, w.z);
-                w.w = fmaf(sigma_draw(rr[i][3]), z.w, w.w);
-            }
-            if (kb >= p.K) w = make_float4(0.f, 0.f, 0.f, 0.f);   // K tail: exact zeros
-            if constexpr (F32) {
-                uint4 o;
-                o.x = __float_as_uint(w.x); o.y = __float_as_uint(w.y);
-                o.z = __float_as_uint(w.z); o.w = __float_as_uint(w.w);
-                *reinterpret_cast<uint4 *>(tile + bpos<true>(row, c) * 16) = o;
-            } else {
-                // unit c: k = 4c..4c+3 -> MFMA lane-q c & 3, elements 4 * (c >> 2) ..
-                uint2 o;
-                o.x = pack_bf16x2(w.x, w.y);
-                o.y = pack_bf16x2(w.z, w.w);
-                *reinterpret_cast<uint2 *>(tile + bpos<false>(row, c & 3) * 16 + (c >> 2) * 8) = o;
-            }
-        }
+    auto dma_A = [&](int stage, int kt) {
+        int k = kt * 32 + 4 * a_chunk;
+        k = k < kmax ? k : kmax;                        // k >= K: clamped (B is exactly 0 there)
+        dma16xN<PW>(asrc, k, aw_addr + (uint32_t)(stage * A_STAGE) * 16u);
     };
 
     f32x4 acc[TM][TN];
@@ -209,8 +268,8 @@ __global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto mfma_step = [&](int stage, int buf) {
-        const uint4 *As = As0 + stage * A_TILE, *Bs = Bs0 + buf * B_TILE;
+    auto mfma_step = [&](int stage, const uint4 *Bs) {
+        const uint4 *As = Aw + stage * A_STAGE;
         if constexpr (F32) {
             uint4 b0[TN], b1[TN];
 #pragma unroll
@@ -221,7 +280,7 @@ __global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                const int row = wave * WTM + a * 16 + fi;
+                const int row = a * 16 + fi;
                 const uint4 a0 = As[row * 8 + (fq ^ (row & 7))];
                 const uint4 a1 = As[row * 8 + ((fq + 4) ^ (row & 7))];
 #pragma unroll
@@ -247,7 +306,7 @@ __global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                const int row = wave * WTM + a * 16 + fi;
+                const int row = a * 16 + fi;
                 const uint4 a0 = As[row * 8 + (fq ^ (row & 7))];
                 const uint4 a1 = As[row * 8 + ((fq + 4) ^ (row & 7))];
                 uint4 af;
@@ -264,38 +323,71 @@ __global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
         }
     };
 
-    // ---- pipeline.  Per wave and per step the VMEM queue gets, in this order, the NA_OPS DMA
-    // pieces of A(k+2) and the NB_OPS raw loads of B(k+2); everything is waited for with ONE
-    // counted s_waitcnt vmcnt(NA_OPS + NB_OPS) per step, one step later: it retires A(k+1) and
-    // raw B(k+1) and leaves tile k+2 in flight across the barrier (raw s_barrier: a
-    // __syncthreads() would drain the DMA queue).
-    //   LDS:  A ring of 3 stages (k in use, k+1 landed/landing, k+2 in flight), drawn B x 2.
-    const int nk = (p.K + BK - 1) / BK;
-    dma_A(0, 0);
-    load_B(rmA, rrA, 0);
-    dma_A(1, BK);
-    load_B(rmB, rrB, BK);
-    wait_B(rmA, rrA);                                   // A(0), raw B(0) landed
-    draw_B(rmA, rrA, 0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    auto step = [&](int kt, f32x4 (&rm_next)[B_PER], f32x4 (&rr_next)[B_PER],
-                    f32x4 (&rm_free)[B_PER], f32x4 (&rr_free)[B_PER]) {
-        // rm_next/rr_next: raw B(kt+1) (in flight or landed); rm_free/rr_free: drawn already
-        int st2 = kt + 2;
-        st2 = st2 % NA_STAGES;
-        dma_A(st2, (kt + 2) * BK);
-        load_B(rm_free, rr_free, (kt + 2) * BK);
-        mfma_step(kt % NA_STAGES, kt & 1);
-        wait_B(rm_next, rr_next);                       // A(kt+1) and raw B(kt+1) landed
-        if (kt + 1 < nk) draw_B(rm_next, rr_next, (kt + 1) & 1, (kt + 1) * BK);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    // ---- VMEM queue of one wave (everything inline asm, so every wait below is ours):
+    //   iteration ch:  R(ch+2) [LPU ops]  then, per step j of the chunk, D(kt + S - 1) [PW ops].
+    //   * raw R(ch+1) (issued at the top of iteration ch-1) is needed by the draw: younger ops are
+    //     that iteration's CH * PW pieces (only (S-1) * PW prologue pieces in iteration 0) and
+    //     R(ch+2)                                   -> vmcnt(min(CH, S-1) * PW + LPU) is safe for both;
+    //   * pieces D(kt) are needed by step kt = ch * CH + j: younger are (S-1) * PW pieces and, when
+    //     D(kt) was issued in the previous iteration (j < S-1), R(ch+2)
+    //                                                            -> vmcnt((S-1) * PW + (j < S-1 ? LPU : 0)).
+    auto iteration = [&](int ch, f32x4 &m_cur, f32x4 &r_cur, f32x4 &m_nxt, f32x4 &r_nxt) {
+        // m_cur/r_cur: raw of chunk ch+LA (in flight); m_nxt/r_nxt: free
+        stamp(0);
+        fetch_unit(m_nxt, r_nxt, ch + LA + 1);
+        if constexpr (B_MODE == B_SAMPLED)
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(m_cur), "+v"(r_cur) : "n"(WAIT_DRAW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(m_cur) : "n"(WAIT_DRAW) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(1);
+        // chunk drawn in this iteration; its buffer held chunk cd - NB, which every wave left at
+        // least one iteration ago when NB > LA + 1 (slack instead of a per-chunk rendezvous)
+        const int cd = ch + LA;
+        if (cd < nch) {
+            if (cd >= NB) lds_wait_ge(&freec[cd % NB], NW * (cd / NB));  // its buffer is free again
+            stamp(2);
+            draw_unit(m_cur, r_cur, cd);
+            publish(cd);
+        }
+        stamp(3);
+        lds_wait_ge(&full[ch % NB], NW * (ch / NB + 1));                // chunk ch drawn by every wave
+        stamp(4);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int kt = ch * CH + j;
+            dma_A((kt + S - 1) % S, kt + S - 1);
+            if (j < S - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 1) * PW + LPU) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 1) * PW) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(kt % S, Bs0 + (ch % NB) * B_CHUNK + j * B_SUB);
+        }
+        if constexpr (STAMPS) { asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[TM - 1][TN - 1])); }
+        stamp(5);
+        // last read of chunk ch by this wave: release the buffer once the reads have returned
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(&freec[ch % NB], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, rmB, rrB, rmA, rrA);
-        if (kt + 1 < nk) step(kt + 1, rmA, rrA, rmB, rrB);
+
+    // prologue: draw chunks 0 .. LA-1, then put the queue in the state the top of iteration 0
+    // expects: [R(LA), D(0) .. D(S-2)]
+#pragma unroll
+    for (int c0 = 0; c0 < LA; ++c0) {
+        fetch_unit(rmB, rrB, c0);
+        if constexpr (B_MODE == B_SAMPLED) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rmB), "+v"(rrB) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rmB) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (c0 < nch) {
+            draw_unit(rmB, rrB, c0);
+            publish(c0);
+        }
+    }
+    fetch_unit(rmA, rrA, LA);
+#pragma unroll
+    for (int j = 0; j < S - 1; ++j) dma_A(j, j);
+    for (int ch = 0; ch < nch; ch += 2) {
+        iteration(ch, rmA, rrA, rmB, rrB);
+        if (ch + 1 < nch) iteration(ch + 1, rmB, rrB, rmA, rrA);
     }
     // nothing may still be writing this workgroup's LDS when it retires
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -318,7 +410,7 @@ __global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
         for (int a = 0; a < TM; ++a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wave * WTM + a * 16 + fq * 4 + r;
+                const int m = m0 + wave * RW + a * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
                 float v = acc[a][b][r] + bias;
                 if (p.flags & BNN_FLAG_RELU) v = fmaxf(v, 0.f);
@@ -328,34 +420,50 @@ __global__ __launch_bounds__(512) void k_linear_v4(const GemmParams p)
     }
 }
 
-template <int BM, int BN, int BMODE, int CP>
-static void launch_v3(GemmParams &p, hipStream_t st)
+template <int NW, int RW, int BN, int CH, int S, int NB, int BMODE, int CP>
+static void launch_sym(GemmParams &p, hipStream_t st)
 {
+    constexpr int BM = NW * RW;
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = (p.N + BN - 1) / BN;
     const int64_t grid = (int64_t)p.ntn * p.ntm * p.S;
-    hipLaunchKernelGGL((k_linear_v4<BM, BN, BMODE, CP>), dim3((unsigned)grid), dim3(512), 0, st, p);
+    if constexpr (BMODE == B_SAMPLED && CP == BNN_COMPUTE_BF16 && BN > 16) {
+        // diagnostic build with in-kernel stamps (tools/stamps.py): BNN_STAMPS=<device pointer>
+        static unsigned long long *dbg = [] { const char *e = getenv("BNN_STAMPS"); return e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }();
+        if (dbg) {
+            p.dbg = dbg;
+            p.dbg_block = 100;
+            hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, true>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
 }
 
 template <int BMODE, int CP>
-static void select_v3(GemmParams &p, hipStream_t st)
+static void select_pc(GemmParams &p, hipStream_t st)
 {
-    // 256 x 80 tiles: 240 workgroups at the BASELINE shape (N = 1200 = 15 x 80, 8 samples x 2
-    // row tiles).  The activation stream (BM x K x 4 B per workgroup through one CU's L1) and the
-    // draw (BN x K per workgroup) are the two costs a tile shape trades; see DESIGN.md.
-    if (p.N <= 16) launch_v3<128, 16, BMODE, CP>(p, st);
-    else launch_v3<256, 80, BMODE, CP>(p, st);
+    static const int tile = [] { const char *e = getenv("BNN_TILE"); return e ? atoi(e) : 0; }();
+    if (p.N <= 16) {
+        launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP>(p, st);                  // 64 x 16 tiles
+    } else if ((CP == BNN_COMPUTE_F32 && tile != 512) || tile == 256) {
+        // fp32 is MFMA-bound: 256 x 80 tiles fill the chip (240 workgroups at the BASELINE shape)
+        launch_sym<16, 16, 80, 1, 3, 4, BMODE, CP>(p, st);
+    } else {
+        // bf16 is draw-bound: 512 x 48 tiles draw every weight of a sample exactly once
+        launch_sym<16, 32, 48, 2, 2, (CP == BNN_COMPUTE_F32 ? 2 : 4), BMODE, CP>(p, st);
+    }
 }
 
 // Called by linear_common (bnn_gemm.hip) when operands are 16-B aligned and K % 4 == 0.
 int dispatch_linear_v2(GemmParams &p, bool sampled, int compute, hipStream_t st, const char *who)
 {
     if (compute == BNN_COMPUTE_F32) {
-        if (sampled) select_v3<B_SAMPLED, BNN_COMPUTE_F32>(p, st);
-        else select_v3<B_PLAIN, BNN_COMPUTE_F32>(p, st);
+        if (sampled) select_pc<B_SAMPLED, BNN_COMPUTE_F32>(p, st);
+        else select_pc<B_PLAIN, BNN_COMPUTE_F32>(p, st);
     } else if (compute == BNN_COMPUTE_BF16) {
-        if (sampled) select_v3<B_SAMPLED, BNN_COMPUTE_BF16>(p, st);
-        else select_v3<B_PLAIN, BNN_COMPUTE_BF16>(p, st);
+        if (sampled) select_pc<B_SAMPLED, BNN_COMPUTE_BF16>(p, st);
+        else select_pc<B_PLAIN, BNN_COMPUTE_BF16>(p, st);
     } else {
         set_error("%s: unknown compute mode %d", who, compute);
         return BNN_E_DTYPE;
