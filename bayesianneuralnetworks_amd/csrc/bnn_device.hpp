@@ -122,10 +122,18 @@ __device__ __forceinline__ float sigma_draw(float rho)
     return 1e-10f + (rho > 20.0f ? rho : sp);
 }
 
-// Same value through the accurate ocml routines (used where ln(sigma) is taken: KL).
+// Same value to ~1e-6 RELATIVE accuracy (used where ln(sigma) is taken: KL, and for
+// WeightNormal.stddev): log1p(e) = log(u) * e / (u - 1), u = 1 + e -- the rounding of u cancels
+// (and log1p(e) = e when u == 1) -- on the native exp2 / log2 / rcp units.
 __device__ __forceinline__ float sigma_accurate(float rho)
 {
-    const float sp = rho > 20.0f ? rho : log1pf(expf(rho));
+    const float e = __builtin_amdgcn_exp2f(rho * 1.44269504088896341f);
+    const float u = 1.0f + e;
+    const float d = u - 1.0f;
+    const float l = __builtin_amdgcn_logf(u) * 0.693147180559945309f;
+    float sp = l * (e * __builtin_amdgcn_rcpf(d));
+    sp = (d == 0.0f) ? e : sp;
+    sp = rho > 20.0f ? rho : sp;
     return 1e-10f + sp;
 }
 

@@ -10,8 +10,8 @@
 namespace bnn {
 
 constexpr int kKlThreads = 256;
-constexpr int kKlPerThread = 16;                       // 4 x float4
-constexpr int kKlChunk = kKlThreads * kKlPerThread;    // 4096 scalars per workgroup
+constexpr int kKlPerThread = 8;                        // 2 x float4
+constexpr int kKlChunk = kKlThreads * kKlPerThread;    // 2048 scalars per workgroup
 constexpr int kKlMaxPerLaunch = 64;
 constexpr int kKlMaxTensors = 128;
 
@@ -43,7 +43,9 @@ __device__ __forceinline__ float kl_elem(float mu, float rho, float pm, float in
     const float r0 = sg * inv_ps;
     const float vr = r0 * r0;
     const float t0 = (mu - pm) * inv_ps;
-    return 0.5f * (vr + t0 * t0 - 1.0f - logf(vr));
+    // ln(vr) = 2 ln(r0) on the native log2 unit (relative 1e-7; |ln| is O(1) or the term is tiny)
+    const float lnvr = __builtin_amdgcn_logf(r0) * (2.0f * 0.693147180559945309f);
+    return 0.5f * (vr + t0 * t0 - 1.0f - lnvr);
 }
 
 __device__ __forceinline__ int find_tensor(const KlLaunch &L, int block)
@@ -168,9 +170,9 @@ extern "C" {
 int64_t bnn_kl_workspace_bytes(int ntensors)
 {
     (void)ntensors;
-    // One double per 4096-scalar chunk; sized for 2^31 scalars in total plus one chunk
+    // One double per 2048-scalar chunk; sized for 2^31 scalars in total plus one chunk
     // of slack per tensor.  (Callers that know their model may pass exactly
-    // 8 * sum_t ceil(n_t / 4096) bytes.)
+    // 8 * sum_t ceil(n_t / 2048) bytes.)
     return 8 * ((int64_t)(1ll << 31) / kKlChunk + kKlMaxTensors);
 }
 

@@ -51,6 +51,7 @@ class _NormalSampling:
     """sample()/.sampled shared by NormalLinear and NormalConvNd (dense.py:46-54, conv.py:65-73)."""
 
     compute = None      # None -> module-wide default (nn.set_compute)
+    activation = None   # 'relu': max(., 0) fused into the kernel epilogue (nn.fuse_activations)
 
     def sample(self, nsamples=1, sample0=0):
         # weight first, then bias (dense.py:47-51); one epoch for the layer's draw
@@ -120,7 +121,8 @@ class NormalLinear(_NormalSampling, BayesianLinear):
             # CPU-resident module: the reference's own op sequence (dense.py:56-60)
             if sample:
                 self.sample()
-            return torch.nn.functional.linear(x, *self.sampled)
+            y = torch.nn.functional.linear(x, *self.sampled)
+            return torch.relu(y) if self.activation == 'relu' else y
         if x.dim() == 1:
             return self.forward(x.unsqueeze(0), sample).squeeze(0)
         S, _, shared, per = self._mc_plan(x, sample)
@@ -133,12 +135,14 @@ class NormalLinear(_NormalSampling, BayesianLinear):
             y = ops.linear_sampled(x2, self.weight.mean, self.weight.scale,
                                    self.bias.mean if self.bias is not None else None,
                                    self.bias.scale if self.bias is not None else None,
-                                   keys[0], keys[1], shared, mode)
+                                   keys[0], keys[1], shared, mode, relu=self.activation == 'relu')
         else:
             # weights were set explicitly (parity mode / user-assigned .sampled)
             w, b = self.sampled
             y = ops.linear_plain(x2, w.unsqueeze(0).expand(S, -1, -1), None if b is None else
                                  b.unsqueeze(0).expand(S, -1), shared, mode)
+            if self.activation == 'relu':
+                y = torch.relu(y)
         return y.reshape(S * per, *lead, y.shape[-1])
 
 

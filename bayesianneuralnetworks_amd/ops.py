@@ -129,7 +129,7 @@ def sample_affine_philox(mu, rho, key):
 
 
 # --------------------------------------------------------------------------- K2 linear
-def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, compute, relu):
+def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, compute, relu=False):
     N, K = mu_w.shape
     S = key_w.nsamples
     y = torch.empty((S, M, N), dtype=torch.float32, device=x2.device)
@@ -146,8 +146,8 @@ class _SampledLinear(torch.autograd.Function):
     """y[s] = x[s] @ w_s^T + b_s, w_s / b_s drawn in-kernel (NormalLinear.forward, dense.py:56-60)."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute):
-        # x: (M, K) shared by all samples, or (S, M, K)
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute, relu):
+        # x: (M, K) shared by all samples, or (S, M, K); relu: max(., 0) fused in the epilogue
         require_cuda_f32(x, "x")
         for t, n in ((mu_w, "weight.mean"), (rho_w, "weight.scale")):
             require_cuda_f32(t, n)
@@ -159,16 +159,18 @@ class _SampledLinear(torch.autograd.Function):
         if K != mu_w.shape[1]:
             raise BnnHipError("linear: input has %d features, weight expects %d" % (K, mu_w.shape[1]))
         y = _linear_sampled_raw(x, 0 if shared_x else M * K, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b,
-                                compute, False)
-        ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None)
+                                compute, relu)
+        ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None, y if relu else None)
         ctx.key_w, ctx.key_b, ctx.shared_x = key_w, key_b, shared_x
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, mu_w, rho_w, rho_b = ctx.saved_tensors
+        x, mu_w, rho_w, rho_b, y_relu = ctx.saved_tensors
         S = ctx.key_w.nsamples
         gy = gy.contiguous()
+        if y_relu is not None:
+            gy = gy * (y_relu > 0).to(gy.dtype)                            # fused ReLU
         gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
         if ctx.needs_input_grad[0]:
             w = _sample_affine_philox_raw(mu_w, rho_w, ctx.key_w)          # (S, N, K), HIP
@@ -182,14 +184,14 @@ class _SampledLinear(torch.autograd.Function):
         if rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
             gb = gy.sum(1)                                                 # (S, N)
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
-        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None
 
 
-def linear_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute="f32"):
+def linear_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute="f32", relu=False):
     return _SampledLinear.apply(x.contiguous(), mu_w.contiguous(), rho_w.contiguous(),
                                 None if mu_b is None else mu_b.contiguous(),
                                 None if rho_b is None else rho_b.contiguous(),
-                                key_w, key_b, shared_x, _compute_code(compute))
+                                key_w, key_b, shared_x, _compute_code(compute), bool(relu))
 
 
 class _PlainLinear(torch.autograd.Function):
@@ -401,7 +403,7 @@ class _KLNormal(torch.autograd.Function):
     """Returns out (T + 1): per-tensor KL SUMS then the KLDivergence scalar (loss.py:16-38)."""
 
     @staticmethod
-    def forward(ctx, n_batches, priors, *params):
+    def forward(ctx, n_batches, priors, out, *params):
         T = len(params) // 2
         mus = [p.detach() for p in params[:T]]
         rhos = [p.detach() for p in params[T:]]
@@ -409,7 +411,13 @@ class _KLNormal(torch.autograd.Function):
             require_cuda_f32(m, "mean")
             require_cuda_f32(r, "scale")
         dev = mus[0].device
-        out = torch.empty(T + 1, dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty(T + 1, dtype=torch.float32, device=dev)
+        else:
+            require_cuda_f32(out, "out")
+            if out.numel() != T + 1:
+                raise BnnHipError("kl_normal: out must hold %d floats" % (T + 1))
+            ctx.mark_dirty(out)
         arr = _kl_descs(mus, rhos, priors)
         check(_lib.load().bnn_kl_forward(arr, T, float(n_batches), ptr(out), ptr(_kl_workspace(dev)),
                                           stream_ptr(dev)), "bnn_kl_forward")
@@ -432,22 +440,30 @@ class _KLNormal(torch.autograd.Function):
         gr = (ctypes.c_void_p * T)(*[t.data_ptr() for t in g_rho])
         check(_lib.load().bnn_kl_backward(arr, T, ctx.n_batches, ptr(up), gm, gr, 0, stream_ptr(up.device)),
               "bnn_kl_backward")
-        return (None, None) + tuple(g_mu) + tuple(g_rho)
+        return (None, None, None) + tuple(g_mu) + tuple(g_rho)
 
 
-def kl_normal(mus, rhos, priors, n_batches=1.0):
-    """priors: list of (prior_mu, prior_sigma) floats.  -> tensor (T + 1)."""
+def kl_normal(mus, rhos, priors, n_batches=1.0, out=None):
+    """priors: list of (prior_mu, prior_sigma) floats.  -> tensor (T + 1): per-tensor KL sums,
+    then the KLDivergence scalar.  `out` (optional, T + 1 floats) receives the result in place."""
     mus = [m.contiguous() for m in mus]
     rhos = [r.contiguous() for r in rhos]
-    return _KLNormal.apply(n_batches, tuple(priors), *mus, *rhos)
+    return _KLNormal.apply(n_batches, tuple(priors), out, *mus, *rhos)
 
 
 # --------------------------------------------------------------------------- MC reduction
-def mc_mean(y):
-    """mean over the leading MC axis: torch.stack(preds).mean(0) (examples/MNIST/uncertainty.py:50)."""
+def mc_mean(y, out=None, scale=None):
+    """scale * sum over the leading MC axis (default scale 1/S = torch.stack(preds).mean(0),
+    examples/MNIST/uncertainty.py:50).  `out` (optional, y[0].numel() floats) is written in place."""
     require_cuda_f32(y, "y")
     S = y.shape[0]
     n = y[0].numel()
-    out = torch.empty(y.shape[1:], dtype=torch.float32, device=y.device)
-    check(_lib.load().bnn_mc_sum(ptr(y), n, S, n, 1.0 / S, ptr(out), 0, stream_ptr(y.device)), "bnn_mc_sum")
+    if out is None:
+        out = torch.empty(y.shape[1:], dtype=torch.float32, device=y.device)
+    else:
+        require_cuda_f32(out, "out")
+        if out.numel() != n:
+            raise BnnHipError("mc_mean: out must hold %d floats" % n)
+    check(_lib.load().bnn_mc_sum(ptr(y), n, S, n, (1.0 / S) if scale is None else float(scale), ptr(out), 0,
+                                 stream_ptr(y.device)), "bnn_mc_sum")
     return out

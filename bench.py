@@ -69,38 +69,52 @@ def build_net(dev, post):
 
     net = MLP().to(dev)
     net.mc_batched = True
+    from bayesianneuralnetworks_amd.nn import fuse_activations
+    fuse_activations(net)            # ReLU folded into the GEMM epilogue (same numerics)
     return net
 
 
 class Step:
-    """One forward of S samples + KL + predictive mean, optionally captured in a HIP graph."""
+    """One forward of S samples + KL + predictive mean, optionally captured in a HIP graph.
+
+    Launches per step: 3 fused sampled-GEMM kernels (ReLU folded into the first two), the
+    multi-tensor KL pair on a side stream (it is eps-independent, so it overlaps the GEMMs),
+    the MC reduction, and the epoch bump.  KL sums and the sum of predictions land directly in
+    the packed buffer that the one collective all-reduces."""
 
     def __init__(self, net, x, rank, world, use_graph):
-        from bayesianneuralnetworks_amd import ops, _lib
+        from bayesianneuralnetworks_amd import ops, _lib, distributed as bd
         from bayesianneuralnetworks_amd._rng import default_generator
-        from bayesianneuralnetworks_amd.nn import KLDivergence
         self.net, self.x, self.rank, self.world = net, x, rank, world
         self.ops, self.lib, self._lib = ops, _lib.load(), _lib
         self.gen = default_generator
-        self.kld = KLDivergence()
         self.graph = None
-        self.packed = None
+        dev = x.device
         self.linears = [m for m in net.layers if hasattr(m, "weight")]
+        # KL: every rank reduces a 1/world slice of every posterior tensor (eps-independent work)
+        self.kl_mu, self.kl_rho = [], []
+        for L in self.linears:
+            for p in (L.weight, L.bias):
+                lo, hi = bd.shard_range(p.mean.numel(), rank, world)
+                if hi > lo:
+                    self.kl_mu.append(p.mean.detach().reshape(-1)[lo:hi])
+                    self.kl_rho.append(p.scale.detach().reshape(-1)[lo:hi])
+        self.T = len(self.kl_mu)
+        self.packed = torch.zeros(self.T + 1 + BATCH * DIMS[-1], device=dev)
+        self.side = torch.cuda.Stream(dev)
         if use_graph:
             self._capture()
 
     def _body(self):
+        dev = self.x.device
         with torch.no_grad():
+            cur = torch.cuda.current_stream(dev)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.ops.kl_normal(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.T, 1.0, out=self.packed[:self.T + 1])
             ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)   # (S, B, 10)
-            out = self.ops.kl_normal([p for L in self.linears for p in (L.weight.mean, L.bias.mean)],
-                                     [p for L in self.linears for p in (L.weight.scale, L.bias.scale)],
-                                     [(0.0, 0.1)] * (2 * len(self.linears)), 1.0)
-            pred = self.ops.mc_mean(ys)
-            # packed buffer of the one collective: [KL sums (6) , KL scalar , sum_s pred_s / S]
-            if self.packed is None:
-                self.packed = torch.empty(out.numel() + pred.numel(), device=self.x.device)
-            self.packed[:out.numel()].copy_(out)
-            self.packed[out.numel():].copy_(pred.reshape(-1))
+            self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / (SAMPLES * self.world))
+            cur.wait_stream(self.side)
         return self.packed
 
     def _capture(self):
@@ -156,7 +170,7 @@ def kernel_roofline(net, x, mode, dev, iters=50):
     launch).  Average launch duration from events on the launch stream; algorithmic FLOPs."""
     from bayesianneuralnetworks_amd import _mc
     layer = net.layers[2]
-    h = torch.randn(SAMPLES * BATCH, DIMS[1], device=dev)
+    h = torch.randn(SAMPLES * BATCH, DIMS[1], device=dev).relu_()
     layer.compute = mode
     with torch.no_grad(), _mc.McContext(SAMPLES, BATCH, 0):
         for _ in range(5):
@@ -175,7 +189,7 @@ def kernel_roofline(net, x, mode, dev, iters=50):
     ach = flops / (ms * 1e-3) / 1e12
     # parameter bytes the launch must touch at least once: mu, rho of W and b
     pbytes = 8.0 * (DIMS[1] * DIMS[2] + DIMS[2])
-    return {"kernel": "k_gemm_nt<sampled> layer2 512x1200x1200 x8 samples", "bound": "mfma",
+    return {"kernel": "k_linear_sym<sampled> layer2 512x1200x1200 x8 samples (one launch)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s", "frac": round(ach / PEAK[mode], 4),
             "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
             "algorithmic_flop_per_launch": flops, "algorithmic_param_bytes_per_launch": pbytes}
@@ -211,7 +225,13 @@ def cpu_baseline(post, x_cpu):
     """The torch-CPU port of the reference (oracle/reference_port.py, pinned bit-for-bit to the
     reference by tests/test_oracle_golden.py) on this machine's host cores."""
     from oracle import reference_port as port
-    cores = os.cpu_count() or 1
+    # threads = the CPU share this process really has (the GPU box gives one GPU 16 cores; asking
+    # torch for all 256 logical CPUs of the host oversubscribes them ~16x)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     with torch.no_grad():
         for _ in range(2):
@@ -287,7 +307,8 @@ def main():
                                    "784-1200-1200-10 NormalLinear MLP, batch 512, 8 MC samples per forward per GPU, "
                                    "exact fp32 MFMA (parity mode)",
                        "samples_per_step_per_gpu": SAMPLES, "batch": BATCH,
-                       "hip_graph": not args.no_graph, "collective": "allreduce 5127 x fp32" if world > 1 else None},
+                       "hip_graph": not args.no_graph,
+                       "collective": "one all-reduce of [6 KL sums, KL scalar, 512x10 prediction sum] fp32" if world > 1 else None},
         }
         if "f32" in results and args.dtype != "f32":
             line["f32"] = {"value": round(results["f32"][0], 1), "ms_per_step": round(results["f32"][1], 4),

@@ -584,3 +584,38 @@ def test_kl_error_and_priors(env):
     net = Net(torch.nn.Sequential(torch.nn.Linear(3, 4), NormalLinear(4, 2), torch.nn.Linear(2, 1))).to(dev)
     r = KLDivergence()(net)
     assert isinstance(r, torch.Tensor) and r.is_cuda and r > 0
+
+
+def test_fused_relu_matches_separate_relu(env):
+    """nn.fuse_activations: ReLU in the kernel epilogue == a ReLU module after the layer,
+    forward and backward (same draw)."""
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule, fuse_activations
+    dev = env["dev"]
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(24, 8, 3)
+            self.layers = torch.nn.Sequential(NormalLinear(24, 40), torch.nn.ReLU(), NormalLinear(40, 8))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    torch.manual_seed(0)
+    net = Net().to(dev)
+    net.mc_batched = True
+    x = torch.randn(10, 24, device=dev, requires_grad=True)
+    env["bnn"].manual_seed(9)
+    ya = net.forward_stacked(x)
+    ya.square().sum().backward()
+    ga = [p.grad.clone() for p in net.parameters()] + [x.grad.clone()]
+    for p in net.parameters():
+        p.grad = None
+    x.grad = None
+    assert fuse_activations(net) == 1 and isinstance(net.layers[1], torch.nn.Identity)
+    env["bnn"].manual_seed(9)
+    yb = net.forward_stacked(x)
+    yb.square().sum().backward()
+    gb = [p.grad.clone() for p in net.parameters()] + [x.grad.clone()]
+    assert torch.equal(ya, yb)
+    for a, b in zip(ga, gb):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
