@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libbnn_hip.so")
 F32, BF16 = 0, 1
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
 FLAG_RELU = 1
+FLAG_X_BF16 = 2
+FLAG_Y_BF16 = 4
 
 
 class BnnHipError(RuntimeError):
@@ -121,6 +123,16 @@ def ptr(t):
     if t is None:
         return None
     return ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda_act(t, name):
+    """activation tensor: contiguous CUDA fp32 or bf16"""
+    if not t.is_cuda:
+        raise BnnHipError("%s must be a CUDA/HIP tensor" % name)
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise BnnHipError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise BnnHipError("%s must be contiguous" % name)
 
 
 def require_cuda_f32(t, name):

@@ -386,7 +386,16 @@ static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
     if (sampled && ((mu_b == nullptr) != (rho_b == nullptr))) { set_error("%s: mu_b / rho_b must both be given or both NULL", who); return BNN_E_NULL; }
     if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldy < N) { set_error("%s: bad extent (M=%lld N=%lld K=%lld S=%d ldx=%lld ldy=%lld)", who, (long long)M, (long long)N, (long long)K, nsamples, (long long)ldx, (long long)ldy); return BNN_E_SHAPE; }
     if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || N * K > ((int64_t)1 << 34)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
-    if (!al4(x) || !al4(y)) { set_error("%s: misaligned pointer", who); return BNN_E_ALIGN; }
+    const bool xh = (flags & BNN_FLAG_X_BF16) != 0, yh = (flags & BNN_FLAG_Y_BF16) != 0;
+    if (!(xh ? (reinterpret_cast<uintptr_t>(x) & 1u) == 0 : al4(x)) || !(yh ? (reinterpret_cast<uintptr_t>(y) & 1u) == 0 : al4(y))) { set_error("%s: misaligned pointer", who); return BNN_E_ALIGN; }
+    if (xh || yh) {
+        // bf16 activations exist only on the fast bf16-compute path
+        const bool ok = compute == BNN_COMPUTE_BF16 && (K % 4 == 0) &&
+                        (!xh || (al16(x) && K % 8 == 0 && ldx % 8 == 0 && x_sample_stride % 8 == 0)) &&
+                        (xh || (al16(x) && ldx % 4 == 0 && x_sample_stride % 4 == 0)) &&
+                        (sampled ? (al16(mu_w) && al16(rho_w)) : (al16(w) && w_sample_stride % 4 == 0));
+        if (!ok) { set_error("%s: BNN_FLAG_X_BF16 / Y_BF16 need bf16 compute, 16-B aligned operands, K %% 8 == 0", who); return BNN_E_UNSUPPORTED; }
+    }
     if (sampled) {
         int rc = check_rng(rng_w, nsamples);
         if (rc) { set_error("%s: bad rng_w", who); return rc; }
@@ -400,7 +409,7 @@ static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
     p.mu_b = sampled ? mu_b : nullptr; p.rho_b = sampled ? rho_b : nullptr;
     p.Y = y; p.y_sample_stride = y_sample_stride; p.ldy = ldy; p.O = (int32_t)N;
     p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.G = 1; p.flags = flags;
-    p.vecA = al16(x) && (ldx % 4 == 0) && (x_sample_stride % 4 == 0);
+    p.vecA = xh ? 1 : (al16(x) && (ldx % 4 == 0) && (x_sample_stride % 4 == 0));
     p.vecB = (K % 4 == 0) && (sampled ? (al16(mu_w) && al16(rho_w)) : (al16(w) && w_sample_stride % 4 == 0));
     if (sampled) { p.rng_w = make_rng(rng_w); p.rng_b = make_rng(mu_b ? rng_b : nullptr); }
     // sampler-paced kernel (bnn_linear.hip) whenever 16-B loads are legal; BNN_LINEAR_KERNEL=v1
@@ -459,13 +468,13 @@ using namespace bnn;
 
 extern "C" {
 
-int bnn_linear_forward_sampled(const float *x, int64_t x_sample_stride, int64_t ldx,
+int bnn_linear_forward_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
                                const float *mu_w, const float *rho_w, const float *mu_b,
-                               const float *rho_b, float *y, int64_t y_sample_stride, int64_t ldy,
+                               const float *rho_b, void *y, int64_t y_sample_stride, int64_t ldy,
                                int64_t M, int64_t N, int64_t K, int nsamples, const bnn_rng_t *rng_w,
                                const bnn_rng_t *rng_b, int compute, int flags, void *stream)
 {
-    return linear_common(x, x_sample_stride, ldx, nullptr, 0, nullptr, 0, mu_w, rho_w, mu_b, rho_b, y,
+    return linear_common((const float *)x, x_sample_stride, ldx, nullptr, 0, nullptr, 0, mu_w, rho_w, mu_b, rho_b, (float *)y,
                          y_sample_stride, ldy, M, N, K, nsamples, rng_w, rng_b, true, compute, flags,
                          stream, "bnn_linear_forward_sampled");
 }

@@ -63,21 +63,22 @@ __device__ __forceinline__ void dma16(const float *src, uint32_t lds_addr)
 // PW pieces with ONE M0 write: the instruction offset is added to BOTH the LDS address and the
 // global address, so piece j uses offset 1024 * j and a source pointer moved back by 1024 * j bytes.
 template <int PW>
-__device__ __forceinline__ void dma16xN(const float *const (&src)[PW], int kofs, uint32_t lds_addr)
+__device__ __forceinline__ void dma16xN(const char *const (&src)[PW], int byte_ofs, uint32_t lds_addr)
 {
     uint32_t keep;
     if constexpr (PW == 1) {
-        const float *p0 = src[0] + kofs;
+        const char *p0 = src[0] + byte_ofs;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(p0), "s"(lds_addr) : "memory");
     } else if constexpr (PW == 2) {
-        const float *p0 = src[0] + kofs, *p1 = src[1] + kofs - 256;
+        const char *p0 = src[0] + byte_ofs, *p1 = src[1] + byte_ofs - 1024;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(p0), "v"(p1), "s"(lds_addr) : "memory");
     } else {
         static_assert(PW == 4, "PW");
-        const float *p0 = src[0] + kofs, *p1 = src[1] + kofs - 256, *p2 = src[2] + kofs - 512, *p3 = src[3] + kofs - 768;
+        const char *p0 = src[0] + byte_ofs, *p1 = src[1] + byte_ofs - 1024, *p2 = src[2] + byte_ofs - 2048,
+                   *p3 = src[3] + byte_ofs - 3072;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
                      "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072\n\ts_mov_b32 m0, %0"
@@ -111,16 +112,21 @@ __device__ __forceinline__ void lds_wait_ge(int *p, int target)
 // private A ring per wave.
 // STAMPS: diagnostic build only (BNN_STAMPS=<device pointer>): wave 0 of block p.dbg_block writes
 // s_memtime stamps to p.dbg; stamps never feed an output value.
-template <int NW, int RW, int BN, int CH, int S, int NB, int B_MODE, int COMPUTE, bool STAMPS = false>
+// ABF: the activations are bf16 in memory (written so by the previous layer's epilogue): half the
+// A stream, half the A ring, and the DMA'd 16-B chunk IS the MFMA fragment (no conversion).
+template <int NW, int RW, int BN, int CH, int S, int NB, int B_MODE, int COMPUTE, bool ABF = false, bool STAMPS = false>
 __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 {
     constexpr bool F32 = (COMPUTE == BNN_COMPUTE_F32);
+    static_assert(!(ABF && F32), "bf16 activations only in bf16 compute mode");
     constexpr int NT = NW * 64;
     constexpr int BM = NW * RW;
     constexpr int TM = RW / 16, TN = BN / 16;
     static_assert(RW % 16 == 0 && BN % 16 == 0, "tile");
-    constexpr int PW = RW / 8;                  // 1-KiB DMA pieces per wave per k-step
-    constexpr int A_STAGE = RW * 8;             // uint4 per wave per stage: RW rows x 8 chunks
+    constexpr int ACH = ABF ? 4 : 8;            // 16-B chunks per A row per 32-k step
+    constexpr int RPP = 64 / ACH;               // rows per 1-KiB DMA piece
+    constexpr int PW = RW / RPP;                // DMA pieces per wave per k-step
+    constexpr int A_STAGE = RW * ACH;           // uint4 per wave per stage
     constexpr int CPR = F32 ? 8 : 4;            // 16-B chunks per B row per 32-k sub-tile
     constexpr int B_SUB = BN * CPR;             // uint4 per sub-tile
     constexpr int B_CHUNK = CH * B_SUB;         // uint4 per chunk buffer
@@ -234,7 +240,10 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
             uint2 o;
             o.x = pack_bf16x2(w.x, w.y);
             o.y = pack_bf16x2(w.z, w.w);
-            *reinterpret_cast<uint2 *>(tile + bpos<false>(u_row, c & 3) * 16 + (c >> 2) * 8) = o;
+            // fp32 A: lane-q holds k = 4q+t, 16+4q+t  -> unit c goes to q = c & 3, half c >> 2
+            // bf16 A: lane-q holds k = 8q .. 8q+7      -> unit c goes to q = c >> 1, half c & 1
+            const int bq = ABF ? (c >> 1) : (c & 3), bh = ABF ? (c & 1) : (c >> 2);
+            *reinterpret_cast<uint2 *>(tile + bpos<false>(u_row, bq) * 16 + bh * 8) = o;
         }
     };
     auto publish = [&](int ch) {
@@ -243,23 +252,27 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     };
 
     // ---- consume side: this wave's RW rows
-    const float *Ab = p.A + (int64_t)s * p.a_sample_stride;
+    constexpr int ESZ = ABF ? 2 : 4;
+    const char *Ab = reinterpret_cast<const char *>(p.A) + (int64_t)s * p.a_sample_stride * ESZ;
     uint4 *Aw = lds + wave * (S * A_STAGE);             // this wave's private ring
     const uint32_t aw_addr = __builtin_amdgcn_readfirstlane(lds_addr_of(Aw));
-    // DMA piece j: rows 8j..8j+7 of this wave's RW; lane l lands at chunk position l & 7 of row
-    // 8j + (l >> 3), so it fetches global chunk (l & 7) ^ (row & 7) (swizzle on the source).
-    const float *asrc[PW];
+    // DMA piece j: rows RPP*j .. of this wave's RW; lane l lands at chunk position l % ACH of row
+    // RPP*j + l / ACH, so it fetches global chunk (l % ACH) ^ swizzle(row) (swizzle on the source;
+    // ACH lanes read one contiguous 128-B (fp32) / 64-B (bf16) row segment).
+    const char *asrc[PW];
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
-        int m = m0 + wave * RW + j * 8 + (lane >> 3);
+        int m = m0 + wave * RW + j * RPP + lane / ACH;
         m = m < p.M ? m : p.M - 1;                      // rows >= M: clamped, outputs never stored
-        asrc[j] = Ab + (int64_t)m * p.lda;
+        asrc[j] = Ab + (int64_t)m * p.lda * ESZ;
     }
-    const int a_chunk = (lane & 7) ^ ((lane >> 3) & 7);
+    const int a_row = lane / ACH;                       // row inside a piece (== row & (RPP-1))
+    const int a_chunk = ABF ? ((lane & 3) ^ ((0x78 >> (((a_row >> 2) & 3) * 2)) & 3)) : ((lane & 7) ^ (a_row & 7));
+    const int a_kmax_bytes = (p.K - 16 / ESZ) * ESZ;    // last legal 16-B chunk of a row
     auto dma_A = [&](int stage, int kt) {
-        int k = kt * 32 + 4 * a_chunk;
-        k = k < kmax ? k : kmax;                        // k >= K: clamped (B is exactly 0 there)
-        dma16xN<PW>(asrc, k, aw_addr + (uint32_t)(stage * A_STAGE) * 16u);
+        int kb = kt * 32 * ESZ + 16 * a_chunk;
+        kb = kb < a_kmax_bytes ? kb : a_kmax_bytes;     // k >= K: clamped (B is exactly 0 there)
+        dma16xN<PW>(asrc, kb, aw_addr + (uint32_t)(stage * A_STAGE) * 16u);
     };
 
     f32x4 acc[TM][TN];
@@ -307,13 +320,17 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int row = a * 16 + fi;
-                const uint4 a0 = As[row * 8 + (fq ^ (row & 7))];
-                const uint4 a1 = As[row * 8 + ((fq + 4) ^ (row & 7))];
                 uint4 af;
-                af.x = pack_bf16x2(__uint_as_float(a0.x), __uint_as_float(a0.y));
-                af.y = pack_bf16x2(__uint_as_float(a0.z), __uint_as_float(a0.w));
-                af.z = pack_bf16x2(__uint_as_float(a1.x), __uint_as_float(a1.y));
-                af.w = pack_bf16x2(__uint_as_float(a1.z), __uint_as_float(a1.w));
+                if constexpr (ABF) {
+                    af = As[bpos<false>(row, fq)];
+                } else {
+                    const uint4 a0 = As[row * 8 + (fq ^ (row & 7))];
+                    const uint4 a1 = As[row * 8 + ((fq + 4) ^ (row & 7))];
+                    af.x = pack_bf16x2(__uint_as_float(a0.x), __uint_as_float(a0.y));
+                    af.y = pack_bf16x2(__uint_as_float(a0.z), __uint_as_float(a0.w));
+                    af.z = pack_bf16x2(__uint_as_float(a1.x), __uint_as_float(a1.y));
+                    af.w = pack_bf16x2(__uint_as_float(a1.z), __uint_as_float(a1.w));
+                }
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
@@ -397,6 +414,8 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     const bool sampled_bias = (p.mu_b != nullptr);
     if (sampled_bias) edev_b = rng_epoch_dev(p.rng_b);
     float *Yb = p.Y + (int64_t)s * p.y_sample_stride;
+    uint16_t *Yh = reinterpret_cast<uint16_t *>(p.Y) + (int64_t)s * p.y_sample_stride;
+    const bool y_bf16 = (p.flags & BNN_FLAG_Y_BF16) != 0;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + b * 16 + fi;
@@ -414,36 +433,45 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                 if (m >= p.M) continue;
                 float v = acc[a][b][r] + bias;
                 if (p.flags & BNN_FLAG_RELU) v = fmaxf(v, 0.f);
-                Yb[(int64_t)m * p.ldy + n] = v;
+                if (y_bf16) Yh[(int64_t)m * p.ldy + n] = f2bf(v);
+                else Yb[(int64_t)m * p.ldy + n] = v;
             }
         }
     }
 }
 
-template <int NW, int RW, int BN, int CH, int S, int NB, int BMODE, int CP>
+template <int NW, int RW, int BN, int CH, int S, int NB, int BMODE, int CP, bool ABF = false>
 static void launch_sym(GemmParams &p, hipStream_t st)
 {
     constexpr int BM = NW * RW;
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = (p.N + BN - 1) / BN;
     const int64_t grid = (int64_t)p.ntn * p.ntm * p.S;
-    if constexpr (BMODE == B_SAMPLED && CP == BNN_COMPUTE_BF16 && BN > 16) {
+    if constexpr (BMODE == B_SAMPLED && CP == BNN_COMPUTE_BF16 && BN > 16 && !ABF) {
         // diagnostic build with in-kernel stamps (tools/stamps.py): BNN_STAMPS=<device pointer>
         static unsigned long long *dbg = [] { const char *e = getenv("BNN_STAMPS"); return e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }();
         if (dbg) {
             p.dbg = dbg;
             p.dbg_block = 100;
-            hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, true>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
+            hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, ABF, true>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
             return;
         }
     }
-    hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, ABF>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
 }
 
 template <int BMODE, int CP>
 static void select_pc(GemmParams &p, hipStream_t st)
 {
     static const int tile = [] { const char *e = getenv("BNN_TILE"); return e ? atoi(e) : 0; }();
+    if constexpr (CP == BNN_COMPUTE_BF16) {
+        if (p.flags & BNN_FLAG_X_BF16) {
+            // bf16 activations: 2-KB stages -> a 3-stage ring and 4 chunk buffers fit easily
+            if (p.N <= 16) launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP, true>(p, st);
+            else launch_sym<16, 32, 48, 2, 3, 4, BMODE, CP, true>(p, st);
+            return;
+        }
+    }
     if (p.N <= 16) {
         launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP>(p, st);                  // 64 x 16 tiles
     } else if ((CP == BNN_COMPUTE_F32 && tile != 512) || tile == 256) {

@@ -52,6 +52,7 @@ class _NormalSampling:
 
     compute = None      # None -> module-wide default (nn.set_compute)
     activation = None   # 'relu': max(., 0) fused into the kernel epilogue (nn.fuse_activations)
+    out_dtype = None    # torch.bfloat16: emit a bf16 hidden activation (bf16 compute mode only)
 
     def sample(self, nsamples=1, sample0=0):
         # weight first, then bias (dense.py:47-51); one epoch for the layer's draw
@@ -132,14 +133,16 @@ class NormalLinear(_NormalSampling, BayesianLinear):
         keys = self._keys(S)
         mode = self._compute_mode()
         if keys is not None:
+            odt = torch.bfloat16 if (self.out_dtype == torch.bfloat16 and mode == "bf16") else torch.float32
             y = ops.linear_sampled(x2, self.weight.mean, self.weight.scale,
                                    self.bias.mean if self.bias is not None else None,
                                    self.bias.scale if self.bias is not None else None,
-                                   keys[0], keys[1], shared, mode, relu=self.activation == 'relu')
+                                   keys[0], keys[1], shared, mode, relu=self.activation == 'relu',
+                                   out_dtype=odt)
         else:
             # weights were set explicitly (parity mode / user-assigned .sampled)
             w, b = self.sampled
-            y = ops.linear_plain(x2, w.unsqueeze(0).expand(S, -1, -1), None if b is None else
+            y = ops.linear_plain(x2.float(), w.unsqueeze(0).expand(S, -1, -1), None if b is None else
                                  b.unsqueeze(0).expand(S, -1), shared, mode)
             if self.activation == 'relu':
                 y = torch.relu(y)

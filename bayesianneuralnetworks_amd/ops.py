@@ -12,7 +12,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BnnHipError, Rng, KlTensor, Conv2dShape, ptr, stream_ptr, check, require_cuda_f32
+from ._lib import (BnnHipError, Rng, KlTensor, Conv2dShape, ptr, stream_ptr, check, require_cuda_f32,
+                   require_cuda_act)
 from ._rng import default_generator, DrawKey
 
 
@@ -129,16 +130,19 @@ def sample_affine_philox(mu, rho, key):
 
 
 # --------------------------------------------------------------------------- K2 linear
-def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, compute, relu=False):
+def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, compute, relu=False,
+                        out_dtype=torch.float32):
     N, K = mu_w.shape
     S = key_w.nsamples
-    y = torch.empty((S, M, N), dtype=torch.float32, device=x2.device)
+    y = torch.empty((S, M, N), dtype=out_dtype, device=x2.device)
     rw = _rng_struct(key_w, x2.device)
     rb = _rng_struct(key_b, x2.device) if mu_b is not None else None
+    flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_X_BF16 if x2.dtype == torch.bfloat16 else 0) | \
+            (_lib.FLAG_Y_BF16 if out_dtype == torch.bfloat16 else 0)
     check(_lib.load().bnn_linear_forward_sampled(
         ptr(x2), x_sample_stride, K, ptr(mu_w), ptr(rho_w), ptr(mu_b), ptr(rho_b),
         ptr(y), M * N, N, M, N, K, S, ctypes.byref(rw), ctypes.byref(rb) if rb is not None else None,
-        compute, _lib.FLAG_RELU if relu else 0, stream_ptr(x2.device)), "bnn_linear_forward_sampled")
+        compute, flags, stream_ptr(x2.device)), "bnn_linear_forward_sampled")
     return y
 
 
@@ -146,9 +150,12 @@ class _SampledLinear(torch.autograd.Function):
     """y[s] = x[s] @ w_s^T + b_s, w_s / b_s drawn in-kernel (NormalLinear.forward, dense.py:56-60)."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute, relu):
-        # x: (M, K) shared by all samples, or (S, M, K); relu: max(., 0) fused in the epilogue
-        require_cuda_f32(x, "x")
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute, relu, out_dtype):
+        # x: (M, K) shared by all samples, or (S, M, K), fp32 or (bf16 compute mode) bf16;
+        # relu: max(., 0) fused in the epilogue; out_dtype: fp32, or bf16 for a hidden activation
+        require_cuda_act(x, "x")
+        if (x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16) and compute != _lib.COMPUTE_BF16:
+            raise BnnHipError("bf16 activations need compute mode 'bf16'")
         for t, n in ((mu_w, "weight.mean"), (rho_w, "weight.scale")):
             require_cuda_f32(t, n)
         if mu_b is not None:
@@ -159,7 +166,7 @@ class _SampledLinear(torch.autograd.Function):
         if K != mu_w.shape[1]:
             raise BnnHipError("linear: input has %d features, weight expects %d" % (K, mu_w.shape[1]))
         y = _linear_sampled_raw(x, 0 if shared_x else M * K, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b,
-                                compute, relu)
+                                compute, relu, out_dtype)
         ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None, y if relu else None)
         ctx.key_w, ctx.key_b, ctx.shared_x = key_w, key_b, shared_x
         return y
@@ -168,7 +175,9 @@ class _SampledLinear(torch.autograd.Function):
     def backward(ctx, gy):
         x, mu_w, rho_w, rho_b, y_relu = ctx.saved_tensors
         S = ctx.key_w.nsamples
-        gy = gy.contiguous()
+        x_dtype = x.dtype
+        x = x.float()
+        gy = gy.float().contiguous()
         if y_relu is not None:
             gy = gy * (y_relu > 0).to(gy.dtype)                            # fused ReLU
         gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
@@ -177,6 +186,7 @@ class _SampledLinear(torch.autograd.Function):
             gx = torch.bmm(gy, w)                                          # (S, M, K)
             if ctx.shared_x:
                 gx = gx.sum(0)
+            gx = gx.to(x_dtype)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             xs = x.unsqueeze(0).expand(S, -1, -1) if ctx.shared_x else x
             gw = torch.bmm(gy.transpose(1, 2), xs)                         # (S, N, K)
@@ -184,14 +194,15 @@ class _SampledLinear(torch.autograd.Function):
         if rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
             gb = gy.sum(1)                                                 # (S, N)
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
-        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None
 
 
-def linear_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute="f32", relu=False):
+def linear_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute="f32", relu=False,
+                   out_dtype=torch.float32):
     return _SampledLinear.apply(x.contiguous(), mu_w.contiguous(), rho_w.contiguous(),
                                 None if mu_b is None else mu_b.contiguous(),
                                 None if rho_b is None else rho_b.contiguous(),
-                                key_w, key_b, shared_x, _compute_code(compute), bool(relu))
+                                key_w, key_b, shared_x, _compute_code(compute), bool(relu), out_dtype)
 
 
 class _PlainLinear(torch.autograd.Function):

@@ -149,11 +149,18 @@ int bnn_kl_backward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batche
  *   x[s] = x + s * x_sample_stride (0 = every sample reads the same input),
  *   y[s] = y + s * y_sample_stride;  ldx / ldy = row strides in elements.
  * flags: BNN_FLAG_RELU applies max(.,0) in the epilogue. */
-enum { BNN_FLAG_RELU = 1 };
-int bnn_linear_forward_sampled(const float *x, int64_t x_sample_stride, int64_t ldx,
+enum {
+    BNN_FLAG_RELU = 1,
+    /* bf16 compute mode only: x is bf16 in memory (ldx, strides in elements; K % 8 == 0,
+     * 16-B aligned) / y is written as bf16.  Lets a chain of layers keep its hidden
+     * activations in bf16: half the activation stream of the next layer. */
+    BNN_FLAG_X_BF16 = 2,
+    BNN_FLAG_Y_BF16 = 4
+};
+int bnn_linear_forward_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
                                const float *mu_w, const float *rho_w,
                                const float *mu_b, const float *rho_b,
-                               float *y, int64_t y_sample_stride, int64_t ldy,
+                               void *y, int64_t y_sample_stride, int64_t ldy,
                                int64_t M, int64_t N, int64_t K, int nsamples,
                                const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
                                int compute, int flags, void *stream);

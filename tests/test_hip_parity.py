@@ -619,3 +619,34 @@ def test_fused_relu_matches_separate_relu(env):
     assert torch.equal(ya, yb)
     for a, b in zip(ga, gb):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_bf16_hidden_activations_are_result_neutral(env):
+    """bf16 compute mode: emitting hidden activations in bf16 (fuse_activations(...,
+    bf16_activations=True)) feeds the consumer the SAME bf16 operand values as fp32 hidden
+    activations would (it rounds its A operand to bf16 either way); only the k order inside the
+    MFMA differs between the two A layouts, i.e. fp32 summation order: 1e-5 of the output scale."""
+    from bayesianneuralnetworks_amd.nn import fuse_activations
+    dev = env["dev"]
+    net, _ = _MLP.build(dev, dims=(96, 200, 120, 10), samples=4, seed=3)
+    net.mc_batched = True
+    fuse_activations(net)
+    x = torch.randn(40, 96, device=dev)
+    env["bnn"].set_compute("bf16")
+    try:
+        env["bnn"].manual_seed(11)
+        ya = net.forward_stacked(x).clone()
+        fuse_activations(net, bf16_activations=True)
+        assert net.layers[0].out_dtype == torch.bfloat16 and net.layers[2].out_dtype == torch.bfloat16
+        assert net.layers[4].out_dtype is None
+        env["bnn"].manual_seed(11)
+        yb = net.forward_stacked(x)
+        assert yb.dtype == torch.float32
+        assert allclose_scaled(N(yb), N(ya))
+        # and in fp32 mode the attribute is ignored (exact path untouched)
+        env["bnn"].set_compute("f32")
+        env["bnn"].manual_seed(11)
+        yc = net.forward_stacked(x)
+        assert yc.dtype == torch.float32 and not torch.equal(yc, yb)
+    finally:
+        env["bnn"].set_compute("f32")
