@@ -60,6 +60,7 @@ SIGNATURES = {
     "bnn_arch": (ctypes.c_char_p, []),
     "bnn_last_error": (ctypes.c_char_p, []),
     "bnn_launch_count": (ctypes.c_uint64, []),
+    "bnn_set_workspace": (_int, [_int, _p, _i64]),
     "bnn_sample_affine_eps": (_int, [_p, _p, _p, _p, _i64, _int, _p]),
     "bnn_sample_affine_philox": (_int, [_p, _p, _p, _i64, _int, _i64, _int, _rngp, _p]),
     "bnn_eps_philox": (_int, [_p, _i64, _int, _i64, _rngp, _p]),
@@ -106,6 +107,20 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_workspaces = {}
+
+
+def ensure_workspace(device):
+    """Register a zeroed 4 MiB scratch tensor for `device` once (split-K tickets + slabs)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _workspaces:
+        ws = torch.zeros(4 << 20, dtype=torch.uint8, device=torch.device("cuda", idx))
+        torch.cuda.synchronize(idx)
+        check(load().bnn_set_workspace(idx, ctypes.c_void_p(ws.data_ptr()), ws.numel()), "bnn_set_workspace")
+        _workspaces[idx] = ws
+    return _workspaces[idx]
 
 
 def check(rc, what):

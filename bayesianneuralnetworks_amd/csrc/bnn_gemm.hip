@@ -372,6 +372,21 @@ static int dispatch(GemmParams &p, bool sampled, int compute, hipStream_t st, co
     return check_launch(who);
 }
 
+// Per-device scratch registered by the host (bnn_set_workspace): [tickets: 64 KiB][slabs: rest].
+static void *g_ws[64];
+static int64_t g_ws_bytes[64];
+constexpr int64_t kTicketBytes = 64 * 1024;
+
+void fill_workspace(GemmParams &p)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_ws[dev] || g_ws_bytes[dev] <= kTicketBytes) return;
+    p.ws_tickets = reinterpret_cast<int *>(g_ws[dev]);
+    p.ws_max_tickets = kTicketBytes / 4;
+    p.ws_slabs = reinterpret_cast<float *>(reinterpret_cast<char *>(g_ws[dev]) + kTicketBytes);
+    p.ws_slab_bytes = g_ws_bytes[dev] - kTicketBytes;
+}
+
 static inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 static inline bool al4(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 3u) == 0; }
 
@@ -415,7 +430,10 @@ static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
     // sampler-paced kernel (bnn_linear.hip) whenever 16-B loads are legal; BNN_LINEAR_KERNEL=v1
     // forces the generic tile kernel (A/B comparisons).
     static const bool force_v1 = [] { const char *e = getenv("BNN_LINEAR_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
-    if (p.vecA && p.vecB && !force_v1) return dispatch_linear_v2(p, sampled, compute, (hipStream_t)stream, who);
+    if (p.vecA && p.vecB && !force_v1) {
+        fill_workspace(p);
+        return dispatch_linear_v2(p, sampled, compute, (hipStream_t)stream, who);
+    }
     return dispatch<A_DENSE>(p, sampled, compute, (hipStream_t)stream, who);
 }
 
@@ -467,6 +485,15 @@ static int conv_common(const float *x, int64_t x_sample_stride, const float *w, 
 using namespace bnn;
 
 extern "C" {
+
+int bnn_set_workspace(int device, void *ptr, int64_t bytes)
+{
+    if (device < 0 || device >= 64) { set_error("bnn_set_workspace: device out of range"); return BNN_E_RANGE; }
+    if (ptr && (bytes < 2 * kTicketBytes || (reinterpret_cast<uintptr_t>(ptr) & 15u))) { set_error("bnn_set_workspace: need >= 128 KiB, 16-B aligned"); return BNN_E_SHAPE; }
+    g_ws[device] = ptr;
+    g_ws_bytes[device] = ptr ? bytes : 0;
+    return BNN_OK;
+}
 
 int bnn_linear_forward_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
                                const float *mu_w, const float *rho_w, const float *mu_b,

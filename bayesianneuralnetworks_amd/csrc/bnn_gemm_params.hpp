@@ -36,10 +36,16 @@ struct GemmParams {
     int32_t flags;
     int32_t vecA, vecB;         // 16-B loads legal
     RngDev rng_w, rng_b;
+    // split-K scratch (bnn_set_workspace): tickets (never reset; last arriver = ticket % KS == KS-1)
+    int *ws_tickets;
+    int64_t ws_max_tickets;
+    float *ws_slabs;
+    int64_t ws_slab_bytes;
     unsigned long long *dbg;    // diagnostic stamps (bnn_linear.hip, STAMPS build), normally NULL
     int32_t dbg_block;
 };
 
 int dispatch_linear_v2(GemmParams &p, bool sampled, int compute, hipStream_t st, const char *who);
+void fill_workspace(GemmParams &p);
 
 }  // namespace bnn

@@ -134,6 +134,7 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
                         out_dtype=torch.float32):
     N, K = mu_w.shape
     S = key_w.nsamples
+    _lib.ensure_workspace(x2.device)
     y = torch.empty((S, M, N), dtype=out_dtype, device=x2.device)
     rw = _rng_struct(key_w, x2.device)
     rb = _rng_struct(key_b, x2.device) if mu_b is not None else None

@@ -173,6 +173,8 @@ def kernel_roofline(net, x, mode, dev, iters=50):
     from bayesianneuralnetworks_amd import _mc
     layer = net.layers[2]
     h = torch.randn(SAMPLES * BATCH, DIMS[1], device=dev).relu_()
+    if mode == "bf16":
+        h = h.bfloat16()          # the hidden activation the step really feeds this layer
     layer.compute = mode
     with torch.no_grad(), _mc.McContext(SAMPLES, BATCH, 0):
         for _ in range(5):
@@ -289,7 +291,10 @@ def main():
     results = {}
     for mode in ([args.dtype] + (["f32"] if args.dtype != "f32" else [])):
         bnn.set_compute(mode)
-        step = Step(net, x, rank, world, not args.no_graph)
+        # bf16 mode: the synthetic batch is resident in HBM as bf16 (the first layer would round its
+        # A operand to bf16 anyway -- identical results, half the input stream); fp32 mode: fp32.
+        x_in = x.bfloat16() if mode == "bf16" else x
+        step = Step(net, x_in, rank, world, not args.no_graph)
         steps = args.steps if mode == args.dtype else max(10, args.steps // 4)
         dt = time_steps(step, steps, args.warmup, world, dev)
         results[mode] = (world * SAMPLES * steps / dt, dt / steps * 1e3, steps)

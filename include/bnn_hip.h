@@ -85,6 +85,12 @@ const char *bnn_last_error(void);    /* text of the last non-zero return on this
  * prove the HIP path ran). */
 uint64_t bnn_launch_count(void);
 
+/* Optional per-device scratch for kernels that split their reduction over workgroups (split-K of
+ * the N <= 16 linear head): `bytes` >= 128 KiB of ZEROED device memory that stays valid until
+ * replaced (ptr = NULL unregisters).  Without it those kernels run unsplit.  Host call, not
+ * stream-ordered: register before launching. */
+int bnn_set_workspace(int device, void *ptr, int64_t bytes);
+
 /* ---- K1: posterior draw --------------------------------------------------
  * replaces  WeightNormal.stddev / WeightNormal.sample
  *           pytorch_bayesian/nn/core.py:25-27, 44-45

@@ -8,13 +8,16 @@ os.environ["BNN_STAMPS"] = hex(dbg.data_ptr())
 from bayesianneuralnetworks_amd import _lib, ops
 from bayesianneuralnetworks_amd._rng import DrawKey
 lib = _lib.load(); S, M, K, N = 8, 512, 1200, 1200
-x = torch.randn(S, M, K, device=dev); mu = torch.randn(N, K, device=dev) * 0.05; rho = torch.full((N, K), -2.0, device=dev)
+x = torch.randn(S, M, K, device=dev)
+if os.environ.get("STAMP_ABF"): x = x.bfloat16()
+mu = torch.randn(N, K, device=dev) * 0.05; rho = torch.full((N, K), -2.0, device=dev)
 mub = torch.zeros(N, device=dev); rhob = torch.full((N,), -2.0, device=dev); y = torch.empty(S, M, N, device=dev)
 kw = ops._rng_struct(DrawKey(1, 1, 0, S, 0), dev); kb = ops._rng_struct(DrawKey(1, 2, 0, S, 0), dev)
 for it in range(3):
     dbg.zero_()
     lib.bnn_linear_forward_sampled(_lib.ptr(x), M * K, K, _lib.ptr(mu), _lib.ptr(rho), _lib.ptr(mub), _lib.ptr(rhob),
-                                   _lib.ptr(y), M * N, N, M, N, K, S, ctypes.byref(kw), ctypes.byref(kb), 1, 0, _lib.stream_ptr(dev))
+                                   _lib.ptr(y), M * N, N, M, N, K, S, ctypes.byref(kw), ctypes.byref(kb), 1,
+                                   2 if x.dtype == torch.bfloat16 else 0, _lib.stream_ptr(dev))
     torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(-1, 2)
 for name, base in (("wave 0", 0),):
