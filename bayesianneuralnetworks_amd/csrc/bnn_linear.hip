@@ -421,6 +421,12 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     if constexpr (KS > 1) {
         // ---- split-K: publish this workgroup's partial tile, last arriver reduces (fixed order)
         const int tile_id = (s * p.ntm + mt) * p.ntn + panel;
+        if (tile_id < 0 || tile_id >= p.ws_max_tickets ||
+            (int64_t)(tile_id + 1) * KS * (BM * BN) * 4 > p.ws_slab_bytes) {
+            // cannot happen when the host sized the workspace (splitk_ok); never index outside it
+            if (tid == 0) p.Y[0] = __int_as_float(0x7fc00000 | (tile_id & 0xffff));
+            return;
+        }
         float *slab0 = p.ws_slabs + (int64_t)tile_id * KS * (BM * BN);
         float *mine = slab0 + (int64_t)ks * (BM * BN);
 #pragma unroll

@@ -30,6 +30,10 @@ P_SCALARS = sum(i * o + o for i, o in zip(DIMS[:-1], DIMS[1:]))          # 2 395
 FLOP_PER_SAMPLE = 2 * BATCH * sum(i * o for i, o in zip(DIMS[:-1], DIMS[1:]))  # 2 450 227 200
 PEAK = {"f32": 157.3, "bf16": 2500.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+# Fabric-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes
+# (profiles/r01_pmc_layer2_bf16.txt): (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 FETCH_SIZE correction
+# applied.  Not measured live (PMC passes serialise kernels); re-collect with tools/pmc.sh.
+TRAFFIC_PMC = {"bf16": 126.6e6, "f32": None}
 
 
 def posteriors(seed=0):
@@ -195,8 +199,10 @@ def kernel_roofline(net, x, mode, dev, iters=50):
     pbytes = 8.0 * (DIMS[1] * DIMS[2] + DIMS[2])
     return {"kernel": "k_linear_sym<sampled> layer2 512x1200x1200 x8 samples (one launch)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s", "frac": round(ach / PEAK[mode], 4),
-            "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
-            "algorithmic_flop_per_launch": flops, "algorithmic_param_bytes_per_launch": pbytes}
+            "traffic": TRAFFIC_PMC.get(mode), "avg_launch_us": round(ms * 1e3, 2),
+            "algorithmic_flop_per_launch": flops, "algorithmic_param_bytes_per_launch": pbytes,
+            "algorithmic_bytes_per_launch": pbytes + SAMPLES * BATCH * (DIMS[1] * (2 if mode == "bf16" else 4) + DIMS[2] * 4),
+            "note": "draw-bound launch: 8 x 1.44 M eps draws at the measured 1.05 Tdraw/s VALU rate = 10.9 us floor"}
 
 
 def sampler_roofline(dev, iters=20):

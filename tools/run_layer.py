@@ -11,6 +11,7 @@ sampled = sys.argv[4] == "sampled"
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 lib = _lib.load(); dev = torch.device("cuda:0"); S, M = 8, 512
 x = torch.randn(S, M, K, device=dev)
+if os.environ.get("ABF"): x = x.bfloat16()
 mu = torch.randn(N, K, device=dev) * 0.05; rho = torch.full((N, K), -2.0, device=dev)
 mub = torch.zeros(N, device=dev); rhob = torch.full((N,), -2.0, device=dev)
 w = torch.randn(S, N, K, device=dev) * 0.05; y = torch.empty(S, M, N, device=dev)
@@ -19,7 +20,7 @@ st = _lib.stream_ptr(dev)
 for _ in range(iters):
     if sampled:
         lib.bnn_linear_forward_sampled(_lib.ptr(x), M * K, K, _lib.ptr(mu), _lib.ptr(rho), _lib.ptr(mub), _lib.ptr(rhob),
-                                       _lib.ptr(y), M * N, N, M, N, K, S, ctypes.byref(kw), ctypes.byref(kb), comp, 0, st)
+                                       _lib.ptr(y), M * N, N, M, N, K, S, ctypes.byref(kw), ctypes.byref(kb), comp, 2 if x.dtype == torch.bfloat16 else 0, st)
     else:
         lib.bnn_linear_forward(_lib.ptr(x), M * K, K, _lib.ptr(w), N * K, None, 0, _lib.ptr(y), M * N, N, M, N, K, S, comp, 0, st)
 torch.cuda.synchronize()
