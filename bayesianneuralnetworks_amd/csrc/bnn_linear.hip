@@ -27,6 +27,7 @@
 // k = 16 + 4q + (t - 4) (t >= 4); B's 4-draw unit c (k = 4c..4c+3) is written for lane-q c & 3,
 // half c >> 2 -- the same permutation on both operands leaves the sum unchanged.
 #include <cstdlib>
+#include <type_traits>
 
 #include "bnn_device.hpp"
 #include "bnn_gemm_params.hpp"
@@ -135,8 +136,9 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     constexpr int B_SUB = BN * CPR;             // uint4 per sub-tile
     constexpr int B_CHUNK = CH * B_SUB;         // uint4 per chunk buffer
     constexpr int UPC = BN * 8 * CH;            // 4-draw units per chunk
-    static_assert(UPC <= NT, "one unit per lane per chunk");
-    constexpr int LPU = (B_MODE == B_SAMPLED ? 2 : 1);   // raw loads per unit
+    constexpr int UPL = (UPC + NT - 1) / NT;    // units per lane per chunk (lane t: units t, t + NT, ..)
+    static_assert(UPL <= 2, "at most two units per lane per chunk");
+    constexpr int LPU = (B_MODE == B_SAMPLED ? 2 : 1) * UPL;   // raw loads per lane per chunk fetch
     constexpr int A_WORDS = NW * S * A_STAGE;
     constexpr int WAIT_DRAW = (CH < S - 1 ? CH : S - 1) * PW + LPU;
     constexpr int LA = NB > 2 ? NB - 2 : 1;     // chunks drawn ahead of the one being consumed
@@ -202,57 +204,79 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     uint32_t edev_w = 0;
     if constexpr (B_MODE == B_SAMPLED) edev_w = rng_epoch_dev(p.rng_w);
     const float *Bsrc = (B_MODE == B_SAMPLED) ? p.mu : p.Bw + (int64_t)s * p.b_sample_stride;
-    const bool draws = tid < UPC;
-    const int u_row = (tid / (8 * CH)) % BN, u_cc = tid % (8 * CH);    // cc = sub * 8 + c
-    int64_t brow;
-    {
-        int n = n0 + u_row;
+    // unit u of a chunk -> (row, cc): row = u / (8 CH), cc = u % (8 CH) = sub * 8 + c
+    struct Raw { f32x4 m[UPL], r[UPL]; };
+    int64_t brow[UPL];
+#pragma unroll
+    for (int i = 0; i < UPL; ++i) {
+        int n = n0 + ((tid + i * NT) / (8 * CH)) % BN;
         n = n < p.N ? n : p.N - 1;              // columns >= N: clamped loads, results never stored
-        brow = (int64_t)n * p.K;
+        brow[i] = (int64_t)n * p.K;
     }
-    f32x4 rmA, rrA, rmB, rrB;                   // raw (mu, rho) of chunk ch+1 / ch+2
-    rrA = rrB = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto fetch_unit = [&](f32x4 &m, f32x4 &r, int ch) {
-        int kb = k_lo + ch * (32 * CH) + 4 * u_cc;
-        kb = kb < kmax ? kb : kmax;             // past K: clamped, drawn as zeros
-        const float *pm = Bsrc + brow + kb;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(m) : "v"(pm) : "memory");
-        if constexpr (B_MODE == B_SAMPLED) {
-            const float *pr = p.rho + brow + kb;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(pr) : "memory");
+    Raw rawA, rawB;                             // raw (mu, rho) of the chunk being drawn / in flight
+#pragma unroll
+    for (int i = 0; i < UPL; ++i) rawA.r[i] = rawB.r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch_unit = [&](Raw &w, int ch) {
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) {
+            const int u_cc = (tid + i * NT) % (8 * CH);
+            int kb = k_lo + ch * (32 * CH) + 4 * u_cc;
+            kb = kb < kmax ? kb : kmax;         // past K: clamped, drawn as zeros
+            const float *pm = Bsrc + brow[i] + kb;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.m[i]) : "v"(pm) : "memory");
+            if constexpr (B_MODE == B_SAMPLED) {
+                const float *pr = p.rho + brow[i] + kb;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.r[i]) : "v"(pr) : "memory");
+            }
         }
     };
-    auto draw_unit = [&](const f32x4 &m, const f32x4 &r, int ch) {
-        if (!draws) return;
-        char *buf = reinterpret_cast<char *>(Bs0 + (ch % NB) * B_CHUNK);
-        const int sub = u_cc >> 3, c = u_cc & 7;
-        const int n = n0 + u_row;
-        const int kb = k_lo + ch * (32 * CH) + 4 * u_cc;
-        float4 w = make_float4(m[0], m[1], m[2], m[3]);
-        if constexpr (B_MODE == B_SAMPLED) {
-            // element index from the UNclamped (n, k): columns >= N draw values nobody reads
-            const int64_t e0 = (int64_t)n * p.K + kb;
-            const float4 z = eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
-            w.x = fmaf(sigma_draw(r[0]), z.x, w.x);
-            w.y = fmaf(sigma_draw(r[1]), z.y, w.y);
-            w.z = fmaf(sigma_draw(r[2]), z.z, w.z);
-            w.w = fmaf(sigma_draw(r[3]), z.w, w.w);
+    // counted wait; the raw registers are operands so that no use of them is scheduled above it
+    auto wait_raw = [&](Raw &w, auto N) {
+        constexpr int n = decltype(N)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory");
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) {
+            asm volatile("" : "+v"(w.m[i]));
+            if constexpr (B_MODE == B_SAMPLED) asm volatile("" : "+v"(w.r[i]));
         }
-        if (kb >= p.K) w = make_float4(0.f, 0.f, 0.f, 0.f);           // K tail: exact zeros
-        char *tile = buf + sub * (B_SUB * 16);
-        if constexpr (F32) {
-            uint4 o;
-            o.x = __float_as_uint(w.x); o.y = __float_as_uint(w.y);
-            o.z = __float_as_uint(w.z); o.w = __float_as_uint(w.w);
-            *reinterpret_cast<uint4 *>(tile + bpos<true>(u_row, c) * 16) = o;
-        } else {
-            uint2 o;
-            o.x = pack_bf16x2(w.x, w.y);
-            o.y = pack_bf16x2(w.z, w.w);
-            // fp32 A: lane-q holds k = 4q+t, 16+4q+t  -> unit c goes to q = c & 3, half c >> 2
-            // bf16 A: lane-q holds k = 8q .. 8q+7      -> unit c goes to q = c >> 1, half c & 1
-            const int bq = ABF ? (c >> 1) : (c & 3), bh = ABF ? (c & 1) : (c >> 2);
-            *reinterpret_cast<uint2 *>(tile + bpos<false>(u_row, bq) * 16 + bh * 8) = o;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto draw_unit = [&](const Raw &w_, int ch) {
+        char *buf = reinterpret_cast<char *>(Bs0 + (ch % NB) * B_CHUNK);
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) {
+            const int u = tid + i * NT;
+            if (u >= UPC) continue;
+            const int u_row = u / (8 * CH), u_cc = u % (8 * CH);
+            const int sub = u_cc >> 3, c = u_cc & 7;
+            const int n = n0 + u_row;
+            const int kb = k_lo + ch * (32 * CH) + 4 * u_cc;
+            float4 w = make_float4(w_.m[i][0], w_.m[i][1], w_.m[i][2], w_.m[i][3]);
+            if constexpr (B_MODE == B_SAMPLED) {
+                // element index from the UNclamped (n, k): columns >= N draw values nobody reads
+                const int64_t e0 = (int64_t)n * p.K + kb;
+                const float4 z = eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
+                w.x = fmaf(sigma_draw(w_.r[i][0]), z.x, w.x);
+                w.y = fmaf(sigma_draw(w_.r[i][1]), z.y, w.y);
+                w.z = fmaf(sigma_draw(w_.r[i][2]), z.z, w.z);
+                w.w = fmaf(sigma_draw(w_.r[i][3]), z.w, w.w);
+            }
+            if (kb >= p.K) w = make_float4(0.f, 0.f, 0.f, 0.f);       // K tail: exact zeros
+            char *tile = buf + sub * (B_SUB * 16);
+            if constexpr (F32) {
+                uint4 o;
+                o.x = __float_as_uint(w.x); o.y = __float_as_uint(w.y);
+                o.z = __float_as_uint(w.z); o.w = __float_as_uint(w.w);
+                *reinterpret_cast<uint4 *>(tile + bpos<true>(u_row, c) * 16) = o;
+            } else {
+                uint2 o;
+                o.x = pack_bf16x2(w.x, w.y);
+                o.y = pack_bf16x2(w.z, w.w);
+                // fp32 A: lane-q holds k = 4q+t, 16+4q+t  -> unit c goes to q = c & 3, half c >> 2
+                // bf16 A: lane-q holds k = 8q .. 8q+7      -> unit c goes to q = c >> 1, half c & 1
+                const int bq = ABF ? (c >> 1) : (c & 3), bh = ABF ? (c & 1) : (c >> 2);
+                *reinterpret_cast<uint2 *>(tile + bpos<false>(u_row, bq) * 16 + bh * 8) = o;
+            }
         }
     };
     auto publish = [&](int ch) {
@@ -357,15 +381,11 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     //   * pieces D(kt) are needed by step kt = ch * CH + j: younger are (S-1) * PW pieces and, when
     //     D(kt) was issued in the previous iteration (j < S-1), R(ch+2)
     //                                                            -> vmcnt((S-1) * PW + (j < S-1 ? LPU : 0)).
-    auto iteration = [&](int ch, f32x4 &m_cur, f32x4 &r_cur, f32x4 &m_nxt, f32x4 &r_nxt) {
-        // m_cur/r_cur: raw of chunk ch+LA (in flight); m_nxt/r_nxt: free
+    auto iteration = [&](int ch, Raw &cur, Raw &nxt) {
+        // cur: raw of chunk ch+LA (in flight); nxt: free
         stamp(0);
-        fetch_unit(m_nxt, r_nxt, ch + LA + 1);
-        if constexpr (B_MODE == B_SAMPLED)
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(m_cur), "+v"(r_cur) : "n"(WAIT_DRAW) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(m_cur) : "n"(WAIT_DRAW) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        fetch_unit(nxt, ch + LA + 1);
+        wait_raw(cur, std::integral_constant<int, WAIT_DRAW>{});
         stamp(1);
         // chunk drawn in this iteration; its buffer held chunk cd - NB, which every wave left at
         // least one iteration ago when NB > LA + 1 (slack instead of a per-chunk rendezvous)
@@ -373,7 +393,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
         if (cd < nch) {
             if (cd >= NB) lds_wait_ge(&freec[cd % NB], NW * (cd / NB));  // its buffer is free again
             stamp(2);
-            draw_unit(m_cur, r_cur, cd);
+            draw_unit(cur, cd);
             publish(cd);
         }
         stamp(3);
@@ -399,21 +419,19 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     // expects: [R(LA), D(0) .. D(S-2)]
 #pragma unroll
     for (int c0 = 0; c0 < LA; ++c0) {
-        fetch_unit(rmB, rrB, c0);
-        if constexpr (B_MODE == B_SAMPLED) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rmB), "+v"(rrB) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rmB) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        fetch_unit(rawB, c0);
+        wait_raw(rawB, std::integral_constant<int, 0>{});
         if (c0 < nch) {
-            draw_unit(rmB, rrB, c0);
+            draw_unit(rawB, c0);
             publish(c0);
         }
     }
-    fetch_unit(rmA, rrA, LA);
+    fetch_unit(rawA, LA);
 #pragma unroll
     for (int j = 0; j < S - 1; ++j) dma_A(j, j);
     for (int ch = 0; ch < nch; ch += 2) {
-        iteration(ch, rmA, rrA, rmB, rrB);
-        if (ch + 1 < nch) iteration(ch + 1, rmB, rrB, rmA, rrA);
+        iteration(ch, rawA, rawB);
+        if (ch + 1 < nch) iteration(ch + 1, rawB, rawA);
     }
     // nothing may still be writing this workgroup's LDS when it retires
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

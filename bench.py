@@ -97,16 +97,24 @@ class Step:
         self.graph = None
         dev = x.device
         self.linears = [m for m in net.layers if hasattr(m, "weight")]
-        # KL: every rank reduces a 1/world slice of every posterior tensor (eps-independent work)
-        self.kl_mu, self.kl_rho = [], []
+        # KL: every rank reduces a 1/world slice of every posterior tensor (eps-independent work).
+        # The packed layout is the same on every rank: [sum_t for the 6 tensors | scalar slot | pred];
+        # a rank whose slice of a small tensor is empty contributes 0 there.
+        self.kl_mu, self.kl_rho, self.kl_idx = [], [], []
+        t = 0
         for L in self.linears:
             for p in (L.weight, L.bias):
                 lo, hi = bd.shard_range(p.mean.numel(), rank, world)
                 if hi > lo:
                     self.kl_mu.append(p.mean.detach().reshape(-1)[lo:hi])
                     self.kl_rho.append(p.scale.detach().reshape(-1)[lo:hi])
-        self.T = len(self.kl_mu)
+                    self.kl_idx.append(t)
+                t += 1
+        self.T = t
+        self.Tl = len(self.kl_idx)
         self.packed = torch.zeros(self.T + 1 + BATCH * DIMS[-1], device=dev)
+        self.kl_tmp = torch.zeros(self.Tl + 1, device=dev)
+        self.kl_pos = torch.tensor(self.kl_idx, device=dev, dtype=torch.long)
         self.side = torch.cuda.Stream(dev)
         if use_graph:
             self._capture()
@@ -117,7 +125,12 @@ class Step:
             cur = torch.cuda.current_stream(dev)
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                self.ops.kl_normal(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.T, 1.0, out=self.packed[:self.T + 1])
+                if self.world == 1:
+                    self.ops.kl_normal(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=self.packed[:self.T + 1])
+                else:
+                    self.ops.kl_normal(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=self.kl_tmp)
+                    self.packed[:self.T + 1].zero_()
+                    self.packed.index_copy_(0, self.kl_pos, self.kl_tmp[:self.Tl])
             ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)   # (S, B, 10)
             self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / (SAMPLES * self.world))
             cur.wait_stream(self.side)
@@ -281,7 +294,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl")
+        # "nccl" = RCCL over xGMI.  BNN_BENCH_BACKEND=gloo only rehearses the N > 1 code path on a
+        # box with fewer GPUs than ranks (ranks then share a card; the number is not a result).
+        torch.distributed.init_process_group(os.environ.get("BNN_BENCH_BACKEND", "nccl"))
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
