@@ -195,6 +195,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 
     if (tid < 2 * NB) full[tid] = 0;
     __syncthreads();
+
     if constexpr (STAMPS) {
         if (p.dbg && (int)blockIdx.x == p.dbg_block && wave == 0) dbg = p.dbg;
     }
