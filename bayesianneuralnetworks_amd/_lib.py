@@ -81,7 +81,7 @@ SIGNATURES = {
                                   _int, _int, _int, _p]),
     "bnn_diag_sampler": (_int, [_p, _int, _int, _int, _p]),
     "bnn_diag_astream": (_int, [_p, _int, _int, _int, _int, _int, _int, _int, _p, _p]),
-    "bnn_mc_sum": (_int, [_p, _i64, _int, _i64, _f, _p, _int, _p]),
+    "bnn_mc_sum": (_int, [_p, _i64, _int, _i64, _f, _p, _int, _p, ctypes.c_uint32, _p]),
 }
 
 _lib = None

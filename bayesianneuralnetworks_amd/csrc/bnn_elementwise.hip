@@ -202,9 +202,11 @@ __global__ void k_rng_advance(uint32_t *epoch_dev, uint32_t inc) { epoch_dev[0] 
 __global__ __launch_bounds__(kThreads) void k_mc_sum(const float *__restrict__ y,
                                                      int64_t y_sample_stride, int nsamples,
                                                      int64_t n, float scale,
-                                                     float *__restrict__ out, int accumulate)
+                                                     float *__restrict__ out, int accumulate,
+                                                     uint32_t *advance_epoch, uint32_t advance_inc)
 {
     const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (advance_epoch && tid == 0) advance_epoch[0] += advance_inc;   // nothing in this kernel draws
     const int64_t nthreads = (int64_t)gridDim.x * kThreads;
     for (int64_t i = tid; i < n; i += nthreads) {
         float a = 0.f;
@@ -376,12 +378,13 @@ int bnn_diag_sampler(float *out, int blocks, int iters, int stage, void *stream)
 }
 
 int bnn_mc_sum(const float *y, int64_t y_sample_stride, int nsamples, int64_t n, float scale,
-               float *out, int accumulate, void *stream)
+               float *out, int accumulate, uint32_t *advance_epoch, uint32_t advance_inc, void *stream)
 {
     if (!y || !out) { set_error("bnn_mc_sum: NULL pointer"); return BNN_E_NULL; }
     if (n < 0 || nsamples < 1) { set_error("bnn_mc_sum: bad extent"); return BNN_E_SHAPE; }
-    if (n == 0) return BNN_OK;
-    hipLaunchKernelGGL(k_mc_sum, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, y, y_sample_stride, nsamples, n, scale, out, accumulate);
+    if (n == 0) return advance_epoch ? bnn_rng_advance(advance_epoch, advance_inc, stream) : BNN_OK;
+    hipLaunchKernelGGL(k_mc_sum, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, y, y_sample_stride,
+                       nsamples, n, scale, out, accumulate, advance_epoch, advance_inc);
     return check_launch("bnn_mc_sum");
 }
 

@@ -90,30 +90,29 @@ __global__ __launch_bounds__(kKlThreads) void k_kl_partial(KlLaunch L, double *_
     }
 }
 
-// One workgroup: per tensor, add its partials in a fixed order; then the scalar of
-// KLDivergence.forward (loss.py:38): mean over tensors of (sum_t / n_t), / n_batches.
+// One workgroup: wave w adds the partials of tensors w, w + 4, ... in a fixed order (lane-strided,
+// then the shuffle tree: no barrier per tensor); then the scalar of KLDivergence.forward
+// (loss.py:38): mean over tensors of (sum_t / n_t), / n_batches, added in tensor order.
 __global__ __launch_bounds__(kKlThreads) void k_kl_final(KlFinal F, const double *__restrict__ partials,
                                                          float *__restrict__ out)
 {
-    __shared__ double red[kKlThreads / 64];
-    __shared__ double total;
-    if (threadIdx.x == 0) total = 0.0;
-    __syncthreads();
-    for (int t = 0; t < F.ntensors; ++t) {
+    __shared__ double means[kKlMaxTensors];
+    const int lane = threadIdx.x & 63;
+    for (int t = threadIdx.x >> 6; t < F.ntensors; t += kKlThreads / 64) {
         double a = 0.0;
-        for (int i = F.first[t] + threadIdx.x; i < F.first[t + 1]; i += kKlThreads) a += partials[i];
+        for (int i = F.first[t] + lane; i < F.first[t + 1]; i += 64) a += partials[i];
         a = wave_sum(a);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s = 0.0;
-            for (int w = 0; w < kKlThreads / 64; ++w) s += red[w];
-            out[t] = (float)s;
-            total += (double)(float)(s / (double)F.n[t]);
+        if (lane == 0) {
+            out[t] = (float)a;
+            means[t] = (double)(float)(a / (double)F.n[t]);
         }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) out[F.ntensors] = (float)((total / (double)F.ntensors) / (double)F.n_batches);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (int t = 0; t < F.ntensors; ++t) total += means[t];
+        out[F.ntensors] = (float)((total / (double)F.ntensors) / (double)F.n_batches);
+    }
 }
 
 __global__ __launch_bounds__(kKlThreads) void k_kl_backward(KlLaunch L, const float *__restrict__ upstream,

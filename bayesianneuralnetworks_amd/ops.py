@@ -464,9 +464,11 @@ def kl_normal(mus, rhos, priors, n_batches=1.0, out=None):
 
 
 # --------------------------------------------------------------------------- MC reduction
-def mc_mean(y, out=None, scale=None):
+def mc_mean(y, out=None, scale=None, advance=None):
     """scale * sum over the leading MC axis (default scale 1/S = torch.stack(preds).mean(0),
-    examples/MNIST/uncertainty.py:50).  `out` (optional, y[0].numel() floats) is written in place."""
+    examples/MNIST/uncertainty.py:50).  `out` (optional, y[0].numel() floats) is written in place.
+    `advance` (optional, a device epoch cell of _rng.EpsGenerator.epoch_dev) is bumped by one in the
+    same launch: the fresh-noise step of a captured MC forward without a launch of its own."""
     require_cuda_f32(y, "y")
     S = y.shape[0]
     n = y[0].numel()
@@ -477,5 +479,6 @@ def mc_mean(y, out=None, scale=None):
         if out.numel() != n:
             raise BnnHipError("mc_mean: out must hold %d floats" % n)
     check(_lib.load().bnn_mc_sum(ptr(y), n, S, n, (1.0 / S) if scale is None else float(scale), ptr(out), 0,
-                                 stream_ptr(y.device)), "bnn_mc_sum")
+                                 ptr(advance) if advance is not None else None, 1, stream_ptr(y.device)),
+          "bnn_mc_sum")
     return out

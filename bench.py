@@ -119,21 +119,45 @@ class Step:
         if use_graph:
             self._capture()
 
+    def _kl(self):
+        if self.world == 1:
+            self.ops.kl_normal(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=self.packed[:self.T + 1])
+        else:
+            self.ops.kl_normal(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=self.kl_tmp)
+            self.packed[:self.T + 1].zero_()
+            self.packed.index_copy_(0, self.kl_pos, self.kl_tmp[:self.Tl])
+
     def _body(self):
+        """KL placement (BNN_BENCH_KL): 'side' forks it at the start of the step, 'after1' forks it
+        behind the first GEMM (so the GEMM is the graph's root node on the main queue), 'serial'
+        keeps everything on one stream."""
         dev = self.x.device
+        mode = os.environ.get("BNN_BENCH_KL", "serial")
         with torch.no_grad():
             cur = torch.cuda.current_stream(dev)
-            self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side):
-                if self.world == 1:
-                    self.ops.kl_normal(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=self.packed[:self.T + 1])
-                else:
-                    self.ops.kl_normal(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=self.kl_tmp)
-                    self.packed[:self.T + 1].zero_()
-                    self.packed.index_copy_(0, self.kl_pos, self.kl_tmp[:self.Tl])
-            ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)   # (S, B, 10)
-            self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / (SAMPLES * self.world))
-            cur.wait_stream(self.side)
+            if mode == "side":
+                self.side.wait_stream(cur)
+                with torch.cuda.stream(self.side):
+                    self._kl()
+            elif mode == "serial":
+                self._kl()
+            hook = None
+            if mode == "after1":
+                def hook(_m, _i, _o):
+                    self.side.wait_stream(cur)
+                    with torch.cuda.stream(self.side):
+                        self._kl()
+                h = self.linears[0].register_forward_hook(hook)
+            try:
+                ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)   # (S, B, 10)
+            finally:
+                if hook is not None:
+                    h.remove()
+            # fresh noise on every replay: the reduction also bumps the device epoch (last kernel of the step)
+            self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / (SAMPLES * self.world),
+                             advance=self.gen.epoch_dev(dev))
+            if mode != "serial":
+                cur.wait_stream(self.side)
         return self.packed
 
     def _capture(self):
@@ -145,13 +169,9 @@ class Step:
                 self._body()
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize()
-        cell = self.gen.epoch_dev(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._body()
-            # fresh noise on every replay: bump the device epoch inside the graph
-            self._lib.check(self.lib.bnn_rng_advance(self._lib.ptr(cell), 1, self._lib.stream_ptr(dev)),
-                            "bnn_rng_advance")
         self.graph = g
 
     def run(self):

@@ -130,8 +130,11 @@ int bnn_rng_advance(uint32_t *epoch_dev, uint32_t inc, void *stream);
  *   kl_e = 0.5 * (r + t - 1 - ln r),  r = (sigma/sigma_p)^2,  t = ((mu - mu_p)/sigma_p)^2
  * out[0..ntensors-1] = per-tensor SUMS (the reference's .mean() = sum / n);
  * out[ntensors]      = mean_t(sum_t / n_t) / n_batches   (loss.py:38).
- * `tensors` is a host array; `workspace` needs bnn_kl_workspace_bytes(ntensors) bytes.
- * Deterministic: fixed-order two-pass reduction, no float atomics. */
+ * `tensors` is a host array; `workspace` needs bnn_kl_workspace_bytes(ntensors) bytes; calls
+ * sharing a workspace must be stream-ordered.
+ * Deterministic: fixed-order two-pass reduction, no float atomics.  (Folding the second pass
+ * into the first behind a last-workgroup ticket was measured SLOWER on MI355X: 23 us against
+ * 6 + 7 us -- 1190 same-address atomics across 8 XCDs serialise.) */
 int64_t bnn_kl_workspace_bytes(int ntensors);
 int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches,
                    float *out, void *workspace, void *stream);
@@ -216,9 +219,13 @@ int bnn_diag_astream(const float *x, int S, int M, int K, int rows_per_wg, int n
 
 /* ---- MC reduction ----------------------------------------------------------
  * replaces  torch.stack(preds).mean(0)   examples/MNIST/uncertainty.py:50
- *   out[i] (+)= scale * sum_s y[s * y_sample_stride + i],  i < n. */
+ *   out[i] (+)= scale * sum_s y[s * y_sample_stride + i],  i < n.
+ * advance_epoch (may be NULL): advance_epoch[0] += advance_inc in the same launch -- the
+ * reduction is the tail of an MC step (every draw of the step has been consumed by the
+ * kernels stream-ordered before it), so this saves the separate bnn_rng_advance launch. */
 int bnn_mc_sum(const float *y, int64_t y_sample_stride, int nsamples, int64_t n,
-               float scale, float *out, int accumulate, void *stream);
+               float scale, float *out, int accumulate, uint32_t *advance_epoch,
+               uint32_t advance_inc, void *stream);
 
 #ifdef __cplusplus
 }

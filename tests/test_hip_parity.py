@@ -172,6 +172,38 @@ def test_kl_is_bitwise_reproducible(env):
     assert np.array_equal(a, b)
 
 
+def test_kl_many_tensors_both_reduction_paths(env):
+    """<= 64 tensors: one partial launch; more: several, sharing the workspace.  Both must match
+    the oracle on ragged tensors, call after call."""
+    dev = env["dev"]
+    gen = torch.Generator().manual_seed(5)
+    sizes = [1, 3, 2047, 2048, 2049, 5000, 7, 64] * 9            # 72 ragged tensors
+    mus = [torch.randn(n, generator=gen) * 0.05 for n in sizes]
+    rhos = [torch.randn(n, generator=gen) * 0.15 - 2 for n in sizes]
+    dm, dr = [m.to(dev) for m in mus], [r.to(dev) for r in rhos]
+    for T_ in (72, 64, 5, 72, 5):                                  # alternate the two paths
+        out = N(env["ops"].kl_normal(dm[:T_], dr[:T_], [(0.0, 0.1)] * T_, 3.0))
+        want = [env["orc"].kl_sum(mus[t].numpy(), rhos[t].numpy(), 0.0, 0.1) for t in range(T_)]
+        for t in range(T_):
+            assert abs(out[t] - want[t]) <= 1e-5 * (1 + abs(want[t])), (T_, t)
+        scalar = np.mean([w / sizes[t] for t, w in enumerate(want)]) / 3.0
+        assert abs(out[T_] - scalar) <= 1e-5 * (1 + abs(scalar))
+
+
+def test_mc_mean_with_epoch_advance(env):
+    """bnn_mc_sum's advance_epoch: the reduction bumps the device epoch cell in the same launch."""
+    dev = env["dev"]
+    y = torch.randn(8, 512, 10, device=dev)
+    cell = torch.zeros(4, dtype=torch.int32, device=dev)
+    out = env["ops"].mc_mean(y, advance=cell)
+    assert allclose(N(out), N(y).mean(0))
+    out2 = env["ops"].mc_mean(y, scale=0.5, advance=cell)
+    assert allclose(N(out2), 0.5 * N(y).sum(0))
+    assert cell.tolist() == [2, 0, 0, 0]
+    env["ops"].mc_mean(y)
+    assert cell.tolist() == [2, 0, 0, 0]
+
+
 # ------------------------------------------------------------------ K2 linear
 def _layer_from_golden(g, dev, cls, *args):
     layer = cls(*args)
