@@ -75,6 +75,15 @@ SIGNATURES = {
                                           _i64, _int, _rngp, _rngp, _int, _int, _p]),
     "bnn_linear_forward": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,
                                   _int, _int, _int, _p]),
+    "bnn_linear_backward_input_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int,
+                                                 _rngp, _int, _int, _p]),
+    "bnn_linear_backward_input": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p]),
+    "bnn_linear_backward_weight_sampled": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64,
+                                                  _int, _rngp, _int, _int, _int, _p]),
+    "bnn_linear_backward_weight": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _int,
+                                          _int, _int, _p]),
+    "bnn_colsum": (_int, [_p, _i64, _i64, _p, _i64, _i64, _int, _int, _p]),
+    "bnn_relu_backward": (_int, [_p, _p, _p, _i64, _int, _p]),
     "bnn_conv2d_forward_sampled": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64,
                                           ctypes.POINTER(Conv2dShape), _int, _rngp, _rngp, _int, _int, _p]),
     "bnn_conv2d_forward": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape),

@@ -495,6 +495,36 @@ int bnn_set_workspace(int device, void *ptr, int64_t bytes)
     return BNN_OK;
 }
 
+int bnn_linear_backward_input_sampled(const void *gy, int64_t gy_sample_stride, int64_t ldgy,
+                                      const float *mu_w, const float *rho_w, void *gx,
+                                      int64_t gx_sample_stride, int64_t ldgx, int64_t M, int64_t N, int64_t K,
+                                      int nsamples, const bnn_rng_t *rng_w, int compute, int flags, void *stream)
+{
+    const char *who = "bnn_linear_backward_input_sampled";
+    if (!gy || !mu_w || !rho_w || !gx) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldgy < N || ldgx < K) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || N * K > ((int64_t)1 << 34)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    const bool gh = (flags & BNN_FLAG_X_BF16) != 0, xh = (flags & BNN_FLAG_Y_BF16) != 0;
+    // the fused kernel streams gy with 16-B LDS-DMA pieces and draws 4 columns of W per Philox block
+    const bool ok = (compute == BNN_COMPUTE_BF16 || (compute == BNN_COMPUTE_F32 && !gh && !xh)) && K % 4 == 0 &&
+                    al16(mu_w) && al16(rho_w) && al16(gy) &&
+                    (gh ? (N % 8 == 0 && ldgy % 8 == 0 && gy_sample_stride % 8 == 0) : (N % 4 == 0 && ldgy % 4 == 0 && gy_sample_stride % 4 == 0)) &&
+                    (xh ? (reinterpret_cast<uintptr_t>(gx) & 1u) == 0 : al4(gx));
+    if (!ok) { set_error("%s: needs K %% 4 == 0, N %% 4 (fp32 gy) / N %% 8 (bf16 gy) == 0, 16-B aligned operands; bf16 only in bf16 compute", who); return BNN_E_UNSUPPORTED; }
+    if (flags & ~(BNN_FLAG_X_BF16 | BNN_FLAG_Y_BF16)) { set_error("%s: unknown flags", who); return BNN_E_UNSUPPORTED; }
+    int rc = check_rng(rng_w, nsamples);
+    if (rc) { set_error("%s: bad rng_w", who); return rc; }
+    if (M == 0) return BNN_OK;
+    GemmParams p{};
+    p.A = reinterpret_cast<const float *>(gy); p.a_sample_stride = gy_sample_stride; p.lda = ldgy;
+    p.mu = mu_w; p.rho = rho_w;
+    p.Y = reinterpret_cast<float *>(gx); p.y_sample_stride = gx_sample_stride; p.ldy = ldgx;
+    p.M = (int32_t)M; p.N = (int32_t)K; p.K = (int32_t)N;           // outputs = columns of W, reduction = rows
+    p.O = p.N; p.S = nsamples; p.G = 1; p.flags = flags; p.vecA = 1; p.vecB = 1;
+    p.rng_w = make_rng(rng_w); p.rng_b = make_rng(nullptr);
+    return dispatch_linear_dgrad(p, compute, (hipStream_t)stream, who);
+}
+
 int bnn_linear_forward_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
                                const float *mu_w, const float *rho_w, const float *mu_b,
                                const float *rho_b, void *y, int64_t y_sample_stride, int64_t ldy,

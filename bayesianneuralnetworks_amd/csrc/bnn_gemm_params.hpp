@@ -5,7 +5,8 @@
 namespace bnn {
 
 enum { A_DENSE = 0, A_IM2COL = 1 };
-enum { B_PLAIN = 0, B_SAMPLED = 1 };
+// B_SAMPLED_T: the drawn matrix is used TRANSPOSED (input gradient: reduction over the weight's rows)
+enum { B_PLAIN = 0, B_SAMPLED = 1, B_SAMPLED_T = 2 };
 
 struct GemmParams {
     // A operand
@@ -46,6 +47,7 @@ struct GemmParams {
 };
 
 int dispatch_linear_v2(GemmParams &p, bool sampled, int compute, hipStream_t st, const char *who);
+int dispatch_linear_dgrad(GemmParams &p, int compute, hipStream_t st, const char *who);
 void fill_workspace(GemmParams &p);
 
 }  // namespace bnn

@@ -31,6 +31,7 @@
 
 #include "bnn_device.hpp"
 #include "bnn_gemm_params.hpp"
+#include "bnn_dma.hpp"
 
 namespace bnn {
 
@@ -45,51 +46,6 @@ __device__ __forceinline__ int bpos(int row, int c)
 {
     if constexpr (F32) return row * 8 + (c ^ (row & 7));
     else return row * 4 + (c ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3));
-}
-
-// One LDS-DMA piece: 64 lanes x 16 B land at LDS byte address lds_addr + 16 * lane (lds_addr
-// wave-uniform, in an SGPR -> M0); every lane supplies its own global source address.
-// Inline asm ON PURPOSE: with __builtin_amdgcn_global_load_lds hipcc knows that LDS is written
-// asynchronously and puts s_waitcnt vmcnt(0) in front of every ds_read of the kernel (measured:
-// the DMA ring drained every k-step).  Here the counted s_waitcnt vmcnt(N) below is the only
-// wait.  M0 is saved / restored inside the statement (it is compiler-reserved).
-__device__ __forceinline__ void dma16(const float *src, uint32_t lds_addr)
-{
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(lds_addr)
-                 : "memory");
-}
-// PW pieces with ONE M0 write: the instruction offset is added to BOTH the LDS address and the
-// global address, so piece j uses offset 1024 * j and a source pointer moved back by 1024 * j bytes.
-template <int PW>
-__device__ __forceinline__ void dma16xN(const char *const (&src)[PW], int byte_ofs, uint32_t lds_addr)
-{
-    uint32_t keep;
-    if constexpr (PW == 1) {
-        const char *p0 = src[0] + byte_ofs;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(p0), "s"(lds_addr) : "memory");
-    } else if constexpr (PW == 2) {
-        const char *p0 = src[0] + byte_ofs, *p1 = src[1] + byte_ofs - 1024;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(p0), "v"(p1), "s"(lds_addr) : "memory");
-    } else {
-        static_assert(PW == 4, "PW");
-        const char *p0 = src[0] + byte_ofs, *p1 = src[1] + byte_ofs - 1024, *p2 = src[2] + byte_ofs - 2048,
-                   *p3 = src[3] + byte_ofs - 3072;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(lds_addr) : "memory");
-    }
-}
-
-__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
-{
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
 }
 
 __device__ __forceinline__ int lds_load(int *p)
@@ -115,6 +71,10 @@ __device__ __forceinline__ void lds_wait_ge(int *p, int target)
 // s_memtime stamps to p.dbg; stamps never feed an output value.
 // ABF: the activations are bf16 in memory (written so by the previous layer's epilogue): half the
 // A stream, half the A ring, and the DMA'd 16-B chunk IS the MFMA fragment (no conversion).
+// B_MODE == B_SAMPLED_T: the input-gradient contraction gx[m][c] = sum_r gy[m][r] * W_s[r][c] -- the
+// reduction runs over the weight's ROWS, so a 4-draw unit (one Philox block = 4 consecutive columns of
+// one row) lands in four LDS rows at one reduction position (4 scalar LDS writes instead of one
+// vector write); p.N = columns of W (outputs here), p.K = rows of W (reduction), row length p.N.
 // KS > 1: split-K -- KS workgroups share one output tile, each reduces a contiguous range of
 // k-chunks into an fp32 slab of the registered workspace; the last arriver (agent-scope release /
 // acquire around one ticket per tile) adds the KS slabs in a FIXED order, so results stay bitwise
@@ -123,6 +83,8 @@ template <int NW, int RW, int BN, int CH, int S, int NB, int B_MODE, int COMPUTE
 __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 {
     constexpr bool F32 = (COMPUTE == BNN_COMPUTE_F32);
+    constexpr bool SAMPLED = (B_MODE != B_PLAIN);
+    constexpr bool BT = (B_MODE == B_SAMPLED_T);
     static_assert(!(ABF && F32), "bf16 activations only in bf16 compute mode");
     constexpr int NT = NW * 64;
     constexpr int BM = NW * RW;
@@ -138,7 +100,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     constexpr int UPC = BN * 8 * CH;            // 4-draw units per chunk
     constexpr int UPL = (UPC + NT - 1) / NT;    // units per lane per chunk (lane t: units t, t + NT, ..)
     static_assert(UPL <= 2, "at most two units per lane per chunk");
-    constexpr int LPU = (B_MODE == B_SAMPLED ? 2 : 1) * UPL;   // raw loads per lane per chunk fetch
+    constexpr int LPU = (SAMPLED ? 2 : 1) * UPL;   // raw loads per lane per chunk fetch
     constexpr int A_WORDS = NW * S * A_STAGE;
     constexpr int WAIT_DRAW = (CH < S - 1 ? CH : S - 1) * PW + LPU;
     constexpr int LA = NB > 2 ? NB - 2 : 1;     // chunks drawn ahead of the one being consumed
@@ -203,16 +165,24 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     // ---- draw side: this lane's unit of every chunk
     const uint32_t sample = p.rng_w.sample0 + (uint32_t)s;
     uint32_t edev_w = 0;
-    if constexpr (B_MODE == B_SAMPLED) edev_w = rng_epoch_dev(p.rng_w);
-    const float *Bsrc = (B_MODE == B_SAMPLED) ? p.mu : p.Bw + (int64_t)s * p.b_sample_stride;
+    if constexpr (SAMPLED) edev_w = rng_epoch_dev(p.rng_w);
+    const float *Bsrc = SAMPLED ? p.mu : p.Bw + (int64_t)s * p.b_sample_stride;
     // unit u of a chunk -> (row, cc): row = u / (8 CH), cc = u % (8 CH) = sub * 8 + c
+    // (B_SAMPLED_T: u -> (r_local, cg) = (u / (BN/4), u % (BN/4)): reduction row, 4-column group)
     struct Raw { f32x4 m[UPL], r[UPL]; };
-    int64_t brow[UPL];
+    constexpr int CG = BN / 4;
+    int64_t brow[UPL];                          // fixed part of the unit's address
 #pragma unroll
     for (int i = 0; i < UPL; ++i) {
-        int n = n0 + ((tid + i * NT) / (8 * CH)) % BN;
-        n = n < p.N ? n : p.N - 1;              // columns >= N: clamped loads, results never stored
-        brow[i] = (int64_t)n * p.K;
+        if constexpr (BT) {
+            int c = n0 + 4 * ((tid + i * NT) % CG);
+            c = c < p.N - 4 ? c : p.N - 4;      // columns >= N: clamped loads, results never stored
+            brow[i] = c;
+        } else {
+            int n = n0 + ((tid + i * NT) / (8 * CH)) % BN;
+            n = n < p.N ? n : p.N - 1;          // columns >= N: clamped loads, results never stored
+            brow[i] = (int64_t)n * p.K;
+        }
     }
     Raw rawA, rawB;                             // raw (mu, rho) of the chunk being drawn / in flight
 #pragma unroll
@@ -220,13 +190,21 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     auto fetch_unit = [&](Raw &w, int ch) {
 #pragma unroll
         for (int i = 0; i < UPL; ++i) {
-            const int u_cc = (tid + i * NT) % (8 * CH);
-            int kb = k_lo + ch * (32 * CH) + 4 * u_cc;
-            kb = kb < kmax ? kb : kmax;         // past K: clamped, drawn as zeros
-            const float *pm = Bsrc + brow[i] + kb;
+            int64_t off;
+            if constexpr (BT) {
+                int r = k_lo + ch * (32 * CH) + ((tid + i * NT) / CG) % (32 * CH);
+                r = r < p.K ? r : p.K - 1;      // past K: clamped, drawn as zeros
+                off = (int64_t)r * p.N + brow[i];
+            } else {
+                const int u_cc = (tid + i * NT) % (8 * CH);
+                int kb = k_lo + ch * (32 * CH) + 4 * u_cc;
+                kb = kb < kmax ? kb : kmax;     // past K: clamped, drawn as zeros
+                off = brow[i] + kb;
+            }
+            const float *pm = Bsrc + off;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.m[i]) : "v"(pm) : "memory");
-            if constexpr (B_MODE == B_SAMPLED) {
-                const float *pr = p.rho + brow[i] + kb;
+            if constexpr (SAMPLED) {
+                const float *pr = p.rho + off;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w.r[i]) : "v"(pr) : "memory");
             }
         }
@@ -238,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 #pragma unroll
         for (int i = 0; i < UPL; ++i) {
             asm volatile("" : "+v"(w.m[i]));
-            if constexpr (B_MODE == B_SAMPLED) asm volatile("" : "+v"(w.r[i]));
+            if constexpr (SAMPLED) asm volatile("" : "+v"(w.r[i]));
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -248,11 +226,41 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
         for (int i = 0; i < UPL; ++i) {
             const int u = tid + i * NT;
             if (u >= UPC) continue;
+            float4 w = make_float4(w_.m[i][0], w_.m[i][1], w_.m[i][2], w_.m[i][3]);
+            if constexpr (BT) {
+                const int r_local = u / CG, cg = u % CG;
+                const int sub = r_local >> 5, rr = r_local & 31;
+                const int r = k_lo + ch * (32 * CH) + r_local;            // weight row = reduction index
+                const int c0 = n0 + 4 * cg;                               // weight column = output column
+                // element index from the UNclamped (r, c0): columns >= N draw values nobody reads
+                const int64_t e0 = (int64_t)r * p.N + c0;
+                const float4 z = eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
+                w.x = fmaf(sigma_draw(w_.r[i][0]), z.x, w.x);
+                w.y = fmaf(sigma_draw(w_.r[i][1]), z.y, w.y);
+                w.z = fmaf(sigma_draw(w_.r[i][2]), z.z, w.z);
+                w.w = fmaf(sigma_draw(w_.r[i][3]), z.w, w.w);
+                if (r >= p.K) w = make_float4(0.f, 0.f, 0.f, 0.f);       // reduction tail: exact zeros
+                char *tile = buf + sub * (B_SUB * 16);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = 4 * cg + j;
+                    if constexpr (F32) {
+                        *reinterpret_cast<float *>(tile + bpos<true>(row, rr >> 2) * 16 + (rr & 3) * 4) = wv[j];
+                    } else {
+                        // position of reduction element rr inside the lane-q fragment (see the fp32-A /
+                        // bf16-A orders below)
+                        const int bq = ABF ? (rr >> 3) : ((rr & 15) >> 2);
+                        const int pos = ABF ? (rr & 7) : ((rr & 3) + 4 * (rr >> 4));
+                        *reinterpret_cast<uint16_t *>(tile + bpos<false>(row, bq) * 16 + pos * 2) = f2bf(wv[j]);
+                    }
+                }
+                continue;
+            }
             const int u_row = u / (8 * CH), u_cc = u % (8 * CH);
             const int sub = u_cc >> 3, c = u_cc & 7;
             const int n = n0 + u_row;
             const int kb = k_lo + ch * (32 * CH) + 4 * u_cc;
-            float4 w = make_float4(w_.m[i][0], w_.m[i][1], w_.m[i][2], w_.m[i][3]);
             if constexpr (B_MODE == B_SAMPLED) {
                 // element index from the UNclamped (n, k): columns >= N draw values nobody reads
                 const int64_t e0 = (int64_t)n * p.K + kb;
@@ -581,6 +589,28 @@ static void select_pc(GemmParams &p, hipStream_t st)
 }
 
 // Called by linear_common (bnn_gemm.hip) when operands are 16-B aligned and K % 4 == 0.
+// Input gradient gx = gy . W_s (W_s re-drawn from the forward's key, used transposed): the same
+// draw-paced pipeline with p.A = gy, p.N = columns of W, p.K = rows of W.
+int dispatch_linear_dgrad(GemmParams &p, int compute, hipStream_t st, const char *who)
+{
+    if (compute == BNN_COMPUTE_F32) {
+        if (p.N <= 16) launch_sym<4, 16, 16, 2, 3, 4, B_SAMPLED_T, BNN_COMPUTE_F32>(p, st);
+        else launch_sym<16, 16, 80, 1, 3, 4, B_SAMPLED_T, BNN_COMPUTE_F32>(p, st);
+    } else if (compute == BNN_COMPUTE_BF16) {
+        if (p.flags & BNN_FLAG_X_BF16) {
+            if (p.N <= 16) launch_sym<4, 16, 16, 2, 3, 4, B_SAMPLED_T, BNN_COMPUTE_BF16, true>(p, st);
+            else launch_sym<16, 32, 48, 2, 3, 4, B_SAMPLED_T, BNN_COMPUTE_BF16, true>(p, st);
+        } else {
+            if (p.N <= 16) launch_sym<4, 16, 16, 2, 3, 4, B_SAMPLED_T, BNN_COMPUTE_BF16>(p, st);
+            else launch_sym<16, 32, 48, 2, 2, 4, B_SAMPLED_T, BNN_COMPUTE_BF16>(p, st);
+        }
+    } else {
+        set_error("%s: unknown compute mode %d", who, compute);
+        return BNN_E_DTYPE;
+    }
+    return check_launch(who);
+}
+
 int dispatch_linear_v2(GemmParams &p, bool sampled, int compute, hipStream_t st, const char *who)
 {
     if (compute == BNN_COMPUTE_F32) {

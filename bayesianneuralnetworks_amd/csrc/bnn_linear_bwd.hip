@@ -1,0 +1,823 @@
+// bnn_linear_bwd.hip -- backward of the sampled linear layer (the reference gets it
+// from autograd through F.linear, dense.py:60, and mu + sigma * eps, core.py:45):
+//
+//   weight gradient, fused with the backward of the draw -- the per-sample dW_s is never stored:
+//       g_mu [n][k]  = sum_s dW_s[n][k]                         dW_s = gy_s^T x_s   (sum over the batch)
+//       g_rho[n][k]  = sum_s dW_s[n][k] * eps_s[n][k] * sigmoid(rho[n][k])
+//     eps_s re-created from the draw's key (the forward's bits), in the accumulator registers.
+//   input gradient with explicit weights (small / unaligned layers; the aligned ones run the fused
+//   draw kernel of bnn_linear.hip in B_SAMPLED_T mode), bias column sums, ReLU mask.
+//
+// k_wgrad: output tile 128 (k) x 64 (n) per 256-thread workgroup, computed TRANSPOSED (rows = k):
+// an MFMA accumulator lane then holds 4 consecutive k of one n -- exactly one Philox block -- so the
+// eps epilogue costs one block per 4 outputs, as in the forward.  Both operands are reduction-major
+// in memory ([m][k] and [m][n]):
+//   bf16: the tiles are staged in LDS as they lie in memory ([32 m][cols], 16-B chunks XOR-swizzled)
+//         and read with ds_read_b64_tr_b16, gfx950's transposing LDS read, which hands every lane the
+//         reduction-contiguous fragment v_mfma_f32_16x16x32_bf16 wants;
+//   fp32: v_mfma_f32_16x16x4_f32 takes one element per lane, so the [m][cols] image is read with
+//         plain ds_read_b32 (rows padded by 16 floats: the four m of a step sit on disjoint banks).
+// Small outputs (N * K small, e.g. the 10-wide head) split the MC samples over gridDim.y; the
+// partials go to the registered workspace and a second kernel adds them in a fixed order.
+#include "bnn_device.hpp"
+#include "bnn_gemm_params.hpp"
+#include "bnn_dma.hpp"
+
+namespace bnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct WgradParams {
+    const void *x;              // (S | 1, M, K) fp32 or bf16
+    int64_t x_sample_stride, ldx;
+    const void *gy;             // (S, M, N) fp32 or bf16
+    int64_t gy_sample_stride, ldgy;
+    const float *rho;           // (N, K)
+    float *g_mu, *g_rho;        // (N, K), or the workspace slabs when nsplit > 1
+    int64_t slab_stride;        // floats between the partials of two sample groups (nsplit > 1)
+    int32_t M, N, K, S, accumulate, ntk, nsplit;
+    int32_t vecX, vecG;         // 16-B loads legal
+    int32_t plain;              // 1: no draw -- out[s] = dW_s per sample (gridDim.y = S), F.linear's own gradient
+    RngDev rng;
+};
+
+constexpr int W_TK = 128, W_TN = 64, W_BM = 32, W_NT = 256;
+
+// Byte offset of 16-B chunk `ch` of row `row` in a [32][cols] bf16 image with ROWB-byte rows.  The
+// XOR keeps the 16-B staging writes and the transposed reads conflict-free (cdna guide T10 (b)).
+template <int ROWB>
+__device__ __forceinline__ int img_off(int row, int ch)
+{
+    constexpr int NCH = ROWB / 16;
+    return ROWB * row + 16 * ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) & (NCH - 1));
+}
+
+__device__ __forceinline__ s16x4 lds_tr_read(const char *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+}
+
+// 8 consecutive elements of one row as packed bf16 (zeros outside the matrix).
+template <bool BF>
+__device__ __forceinline__ uint4 load8_bf16(const void *base, int64_t row_off, int col, int ncols, bool row_ok, bool vec)
+{
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (!row_ok || col >= ncols) return o;
+    if constexpr (BF) {
+        const uint16_t *q = reinterpret_cast<const uint16_t *>(base) + row_off + col;
+        if (vec && col + 8 <= ncols) return *reinterpret_cast<const uint4 *>(q);
+        uint16_t h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (col + j < ncols) ? q[j] : (uint16_t)0;
+        o.x = h[0] | ((uint32_t)h[1] << 16); o.y = h[2] | ((uint32_t)h[3] << 16);
+        o.z = h[4] | ((uint32_t)h[5] << 16); o.w = h[6] | ((uint32_t)h[7] << 16);
+        return o;
+    } else {
+        const float *q = reinterpret_cast<const float *>(base) + row_off + col;
+        float f[8];
+        if (vec && col + 8 <= ncols) {
+            const float4 a = *reinterpret_cast<const float4 *>(q), b = *reinterpret_cast<const float4 *>(q + 4);
+            f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (col + j < ncols) ? q[j] : 0.f;
+        }
+        o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+        o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+        return o;
+    }
+}
+
+__device__ __forceinline__ float4 load4_f32(const float *base, int64_t row_off, int col, int ncols, bool row_ok, bool vec)
+{
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!row_ok || col >= ncols) return o;
+    const float *q = base + row_off + col;
+    if (vec && col + 4 <= ncols) return *reinterpret_cast<const float4 *>(q);
+    o.x = q[0];
+    if (col + 1 < ncols) o.y = q[1];
+    if (col + 2 < ncols) o.z = q[2];
+    if (col + 3 < ncols) o.w = q[3];
+    return o;
+}
+
+// Shared tail of both kernels.  Accumulator element acc[a][b][r] is output (n, k):
+//   n = n0 + wn * 32 + b * 16 + (lane & 15),  k = k0 + wk * 64 + a * 16 + 4 * (lane >> 4) + r.
+struct WgradAcc {
+    f32x4 acc[4][2], gmu[4][2], grho[4][2];
+};
+
+__device__ __forceinline__ void wgrad_sample_end(WgradAcc &A, const WgradParams &p, uint32_t edev, int s, int nb, int kb)
+{
+    const int lane = threadIdx.x & 63;
+    const bool k4 = (p.K & 3) == 0;              // rows start on a Philox block: one block per 4 outputs
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = nb + b * 16 + (lane & 15), k = kb + a * 16 + 4 * (lane >> 4);
+            if (n < p.N && k < p.K) {
+                A.gmu[a][b] += A.acc[a][b];
+                if (!p.plain) {
+                    const int64_t e0 = (int64_t)n * p.K + k;
+                    const uint32_t sample = p.rng.sample0 + (uint32_t)s;
+                    float4 z;
+                    if (k4) {
+                        z = eps4(p.rng, edev, (uint32_t)(e0 >> 2), sample);
+                    } else {                     // odd K: element by element (columns past K are discarded)
+                        z.x = eps1(p.rng, edev, (uint64_t)e0, sample);
+                        z.y = eps1(p.rng, edev, (uint64_t)e0 + 1, sample);
+                        z.z = eps1(p.rng, edev, (uint64_t)e0 + 2, sample);
+                        z.w = eps1(p.rng, edev, (uint64_t)e0 + 3, sample);
+                    }
+                    A.grho[a][b][0] = fmaf(A.acc[a][b][0], z.x, A.grho[a][b][0]);
+                    A.grho[a][b][1] = fmaf(A.acc[a][b][1], z.y, A.grho[a][b][1]);
+                    A.grho[a][b][2] = fmaf(A.acc[a][b][2], z.z, A.grho[a][b][2]);
+                    A.grho[a][b][3] = fmaf(A.acc[a][b][3], z.w, A.grho[a][b][3]);
+                }
+            }
+            A.acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);   // one Philox block at a time: 8 interleaved ones spill
+        }
+}
+
+__device__ __forceinline__ void wgrad_store(const WgradAcc &A, const WgradParams &p, int nb, int kb)
+{
+    const int lane = threadIdx.x & 63;
+    const bool k4 = (p.K & 3) == 0;
+    const bool final_pass = p.nsplit == 1 && !p.plain;
+    float *om = p.g_mu, *orho = p.g_rho;
+    if (!final_pass) {                           // raw partials / per-sample dW
+        om = p.g_mu + (int64_t)blockIdx.y * p.slab_stride;
+        orho = om + (int64_t)p.N * p.K;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = nb + b * 16 + (lane & 15), k = kb + a * 16 + 4 * (lane >> 4);
+            if (n >= p.N || k >= p.K) continue;
+            const int64_t e0 = (int64_t)n * p.K + k;
+            float gm[4] = {A.gmu[a][b][0], A.gmu[a][b][1], A.gmu[a][b][2], A.gmu[a][b][3]};
+            float gr[4] = {A.grho[a][b][0], A.grho[a][b][1], A.grho[a][b][2], A.grho[a][b][3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k + r >= p.K) continue;
+                if (final_pass) {
+                    gr[r] *= dsoftplus(p.rho[e0 + r]);
+                    if (p.accumulate) { gm[r] += om[e0 + r]; gr[r] += orho[e0 + r]; }
+                } else if (p.plain && p.accumulate) {
+                    gm[r] += om[e0 + r];
+                }
+            }
+            if (k4) {                            // 4 consecutive k of one row, 16-B aligned
+                *reinterpret_cast<float4 *>(om + e0) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+                if (!p.plain) *reinterpret_cast<float4 *>(orho + e0) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (k + r >= p.K) continue;
+                    om[e0 + r] = gm[r];
+                    if (!p.plain) orho[e0 + r] = gr[r];
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------ bf16 operands, fp32 accumulate
+template <bool XBF, bool GBF>
+__global__ __launch_bounds__(W_NT, 2) void k_wgrad_bf16(const WgradParams p)
+{
+    constexpr int XB = W_BM * W_TK * 2, GB = W_BM * W_TN * 2;     // 8 KB + 4 KB per buffer
+    __shared__ __attribute__((aligned(16))) char lds[2 * (XB + GB)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;                       // 2 x 2 waves, 64 k x 32 n each
+    const int kt = blockIdx.x % p.ntk, nt = blockIdx.x / p.ntk;
+    const int k0 = kt * W_TK, n0 = nt * W_TN;
+    const int s_lo = (int)((int64_t)blockIdx.y * p.S / p.nsplit), s_hi = (int)((int64_t)(blockIdx.y + 1) * p.S / p.nsplit);
+    const int msteps = (p.M + W_BM - 1) / W_BM;
+    const int total = (s_hi - s_lo) * msteps;
+    const uint32_t edev = rng_epoch_dev(p.rng);
+
+    // staging: X tile 32 x 16 chunks = 512 (2 per thread), G tile 32 x 8 chunks = 256 (1 per thread)
+    const int xr0 = tid >> 4, xch = tid & 15;                      // rows xr0 and xr0 + 16
+    const int gr0 = tid >> 3, gch = tid & 7;
+    uint4 sx[2], sg;
+    auto fetch = [&](int t) {
+        const int s = s_lo + t / msteps, m0 = (t % msteps) * W_BM;
+        const int64_t xs = (int64_t)s * p.x_sample_stride, gs = (int64_t)s * p.gy_sample_stride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + xr0 + 16 * i;
+            sx[i] = load8_bf16<XBF>(p.x, xs + (int64_t)m * p.ldx, k0 + 8 * xch, p.K, m < p.M, p.vecX != 0);
+        }
+        const int m = m0 + gr0;
+        sg = load8_bf16<GBF>(p.gy, gs + (int64_t)m * p.ldgy, n0 + 8 * gch, p.N, m < p.M, p.vecG != 0);
+    };
+    auto stage = [&](int buf) {
+        char *X = lds + buf * (XB + GB), *G = X + XB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4 *>(X + img_off<256>(xr0 + 16 * i, xch)) = sx[i];
+        *reinterpret_cast<uint4 *>(G + img_off<128>(gr0, gch)) = sg;
+    };
+
+    WgradAcc A;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) A.acc[a][b] = A.gmu[a][b] = A.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addressing: lane = 16 Q + 4 q + pp supplies row (8Q [+4] + q), columns 4 pp .. 4 pp + 3
+    // of a 16-column block and receives column (lane & 15), rows 8Q [+4] .. +3
+    const int Q = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    auto compute = [&](int buf) {
+        const char *X = lds + buf * (XB + GB), *G = X + XB;
+        s16x8 af[4], bfr[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int c0 = (wk * 64 + a * 16) / 8 + (pp >> 1);
+            const s16x4 lo = lds_tr_read(X + img_off<256>(8 * Q + q, c0) + 8 * (pp & 1));
+            const s16x4 hi = lds_tr_read(X + img_off<256>(8 * Q + 4 + q, c0) + 8 * (pp & 1));
+            af[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c0 = (wn * 32 + b * 16) / 8 + (pp >> 1);
+            const s16x4 lo = lds_tr_read(G + img_off<128>(8 * Q + q, c0) + 8 * (pp & 1));
+            const s16x4 hi = lds_tr_read(G + img_off<128>(8 * Q + 4 + q, c0) + 8 * (pp & 1));
+            bfr[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                A.acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
+                                                                      __builtin_bit_cast(bf16x8, bfr[b]), A.acc[a][b], 0, 0, 0);
+    };
+
+    const int nb = n0 + wn * 32, kb = k0 + wk * 64;
+    if (total > 0) {
+        fetch(0);
+        stage(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) fetch(t + 1);
+        compute(t & 1);
+        if (t + 1 < total) stage((t + 1) & 1);
+        __syncthreads();
+        if ((t + 1) % msteps == 0) wgrad_sample_end(A, p, edev, s_lo + t / msteps, nb, kb);
+    }
+    wgrad_store(A, p, nb, kb);
+}
+
+// Same contraction for the hot case -- x and gy both bf16 in memory, M % 32 == 0, K % 8 == 0, N % 8 == 0:
+// the [32 m][cols] images ARE the memory layout, so LDS-DMA (global_load_lds_dwordx4) fills them
+// without touching registers, the XOR swizzle applied on the source side (lane l of a 1-KiB piece
+// fetches the chunk that belongs in LDS slot l).  4-deep ring, three steps in flight per wave, one
+// barrier per step; wave w owns X pieces 2w, 2w+1 and G piece w of every step (rows 8w .. 8w+7).
+// Columns past K / N are fetched from the last legal chunk: they only feed outputs that are discarded.
+__global__ __launch_bounds__(W_NT, 2) void k_wgrad_bf16_dma(const WgradParams p)
+{
+    constexpr int XB = W_BM * W_TK * 2, GB = W_BM * W_TN * 2, NBUF = 4, OPS = 3;
+    __shared__ __attribute__((aligned(1024))) char lds[NBUF * (XB + GB)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 1, wn = wave & 1;
+    const int kt = blockIdx.x % p.ntk, nt = blockIdx.x / p.ntk;
+    const int k0 = kt * W_TK, n0 = nt * W_TN;
+    const int s_lo = (int)((int64_t)blockIdx.y * p.S / p.nsplit), s_hi = (int)((int64_t)(blockIdx.y + 1) * p.S / p.nsplit);
+    const int msteps = p.M / W_BM;
+    const int total = (s_hi - s_lo) * msteps;
+    const uint32_t edev = rng_epoch_dev(p.rng);
+
+    const char *xsrc[2], *gsrc;
+    {
+        const int sc = lane & 15;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * wave + 4 * j + (lane >> 4);
+            int col = k0 + 8 * (sc ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+            col = col < p.K - 8 ? col : p.K - 8;
+            xsrc[j] = reinterpret_cast<const char *>(p.x) + ((int64_t)row * p.ldx + col) * 2;
+        }
+        const int grow = 8 * wave + (lane >> 3), gsc = lane & 7;
+        int gcol = n0 + 8 * (gsc ^ ((((grow & 3) << 2) | ((grow >> 2) & 3)) & 7));
+        gcol = gcol < p.N - 8 ? gcol : p.N - 8;
+        gsrc = reinterpret_cast<const char *>(p.gy) + ((int64_t)grow * p.ldgy + gcol) * 2;
+    }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    auto issue = [&](int t) {
+        const int tt = t < total ? t : total - 1;                  // past the end: harmless re-fetch (keeps vmcnt uniform)
+        const int s = s_lo + tt / msteps, m0 = (tt % msteps) * W_BM;
+        const int64_t xo = ((int64_t)s * p.x_sample_stride + (int64_t)m0 * p.ldx) * 2;
+        const int64_t go = ((int64_t)s * p.gy_sample_stride + (int64_t)m0 * p.ldgy) * 2;
+        const uint32_t base = lds0 + (uint32_t)(t % NBUF) * (XB + GB);
+        const char *xs2[2] = {xsrc[0] + xo, xsrc[1] + xo};
+        dma16xN<2>(xs2, 0, base + (uint32_t)wave * 2048u);
+        dma16(reinterpret_cast<const float *>(gsrc + go), base + XB + (uint32_t)wave * 1024u);
+    };
+
+    WgradAcc A;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) A.acc[a][b] = A.gmu[a][b] = A.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int Q = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int aoff[4][2], boff[2][2];                                    // tr-read byte offsets, fixed over the loop
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int c0 = (wk * 64 + a * 16) / 8 + (pp >> 1);
+        aoff[a][0] = img_off<256>(8 * Q + q, c0) + 8 * (pp & 1);
+        aoff[a][1] = img_off<256>(8 * Q + 4 + q, c0) + 8 * (pp & 1);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int c0 = (wn * 32 + b * 16) / 8 + (pp >> 1);
+        boff[b][0] = XB + img_off<128>(8 * Q + q, c0) + 8 * (pp & 1);
+        boff[b][1] = XB + img_off<128>(8 * Q + 4 + q, c0) + 8 * (pp & 1);
+    }
+    auto compute = [&](int buf) {
+        const char *X = lds + buf * (XB + GB);
+        s16x8 af[4], bfr[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            af[a] = __builtin_shufflevector(lds_tr_read(X + aoff[a][0]), lds_tr_read(X + aoff[a][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            bfr[b] = __builtin_shufflevector(lds_tr_read(X + boff[b][0]), lds_tr_read(X + boff[b][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                A.acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
+                                                                      __builtin_bit_cast(bf16x8, bfr[b]), A.acc[a][b], 0, 0, 0);
+    };
+
+    const int nb = n0 + wn * 32, kb = k0 + wk * 64;
+    if (total > 0) {
+#pragma unroll
+        for (int t = 0; t < NBUF - 1; ++t) issue(t);
+        for (int t = 0; t < total; ++t) {
+            // this wave's pieces of step t have landed (steps t+1, t+2 may still be in flight) ...
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * OPS) : "memory");
+            __syncthreads();                                       // ... and everyone else's; buffer (t-1) % NBUF is free
+            issue(t + NBUF - 1);
+            compute(t % NBUF);
+            if ((t + 1) % msteps == 0) wgrad_sample_end(A, p, edev, s_lo + t / msteps, nb, kb);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may still be writing this LDS at exit
+    }
+    wgrad_store(A, p, nb, kb);
+}
+
+// ------------------------------------------------------------------ exact fp32
+__global__ __launch_bounds__(W_NT) void k_wgrad_f32(const WgradParams p)
+{
+    constexpr int XLD = W_TK + 16, GLD = W_TN + 16;                // padded rows (floats)
+    constexpr int XF = W_BM * XLD, GF = W_BM * GLD;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (XF + GF)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int kt = blockIdx.x % p.ntk, nt = blockIdx.x / p.ntk;
+    const int k0 = kt * W_TK, n0 = nt * W_TN;
+    const int s_lo = (int)((int64_t)blockIdx.y * p.S / p.nsplit), s_hi = (int)((int64_t)(blockIdx.y + 1) * p.S / p.nsplit);
+    const int msteps = (p.M + W_BM - 1) / W_BM;
+    const int total = (s_hi - s_lo) * msteps;
+    const uint32_t edev = rng_epoch_dev(p.rng);
+    const float *xp = reinterpret_cast<const float *>(p.x), *gp = reinterpret_cast<const float *>(p.gy);
+
+    // staging: X tile 32 x 32 float4 = 1024 (4 per thread), G tile 32 x 16 float4 = 512 (2 per thread)
+    const int xr0 = tid >> 5, xc4 = tid & 31;                      // rows xr0 + 8 i
+    const int gr0 = tid >> 4, gc4 = tid & 15;                      // rows gr0 + 16 i
+    float4 sx[4], sg[2];
+    auto fetch = [&](int t) {
+        const int s = s_lo + t / msteps, m0 = (t % msteps) * W_BM;
+        const int64_t xs = (int64_t)s * p.x_sample_stride, gs = (int64_t)s * p.gy_sample_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + xr0 + 8 * i;
+            sx[i] = load4_f32(xp, xs + (int64_t)m * p.ldx, k0 + 4 * xc4, p.K, m < p.M, p.vecX != 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + gr0 + 16 * i;
+            sg[i] = load4_f32(gp, gs + (int64_t)m * p.ldgy, n0 + 4 * gc4, p.N, m < p.M, p.vecG != 0);
+        }
+    };
+    auto stage = [&](int buf) {
+        float *X = lds + buf * (XF + GF), *G = X + XF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(X + (xr0 + 8 * i) * XLD + 4 * xc4) = sx[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(G + (gr0 + 16 * i) * GLD + 4 * gc4) = sg[i];
+    };
+
+    WgradAcc A;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) A.acc[a][b] = A.gmu[a][b] = A.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int Q = lane >> 4, g = lane & 15;
+    auto compute = [&](int buf) {
+        const float *X = lds + buf * (XF + GF), *G = X + XF;
+#pragma unroll
+        for (int mm = 0; mm < W_BM / 4; ++mm) {
+            float av[4], bv[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = X[(4 * mm + Q) * XLD + wk * 64 + a * 16 + g];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bv[b] = G[(4 * mm + Q) * GLD + wn * 32 + b * 16 + g];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    A.acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], A.acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const int nb = n0 + wn * 32, kb = k0 + wk * 64;
+    if (total > 0) {
+        fetch(0);
+        stage(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) fetch(t + 1);
+        compute(t & 1);
+        if (t + 1 < total) stage((t + 1) & 1);
+        __syncthreads();
+        if ((t + 1) % msteps == 0) wgrad_sample_end(A, p, edev, s_lo + t / msteps, nb, kb);
+    }
+    wgrad_store(A, p, nb, kb);
+}
+
+// Fixed-order sum of the sample-group partials (nsplit > 1), then sigmoid(rho) on the rho part.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ slabs, int64_t slab_stride, int nsplit,
+                                                      const float *__restrict__ rho, float *__restrict__ g_mu,
+                                                      float *__restrict__ g_rho, int64_t n, int accumulate)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float gm = 0.f, gr = 0.f;
+    for (int g = 0; g < nsplit; ++g) {
+        gm += slabs[(int64_t)g * slab_stride + e];
+        gr += slabs[(int64_t)g * slab_stride + n + e];
+    }
+    gr *= dsoftplus(rho[e]);
+    if (accumulate) { gm += g_mu[e]; gr += g_rho[e]; }
+    g_mu[e] = gm;
+    g_rho[e] = gr;
+}
+
+// ------------------------------------------------------------------ input gradient, explicit weights
+// gx[s][m][k0..k0+3] = sum_n gy[s][m][n] * w[s][n][k0..k0+3]; one thread per (s, m, 4 columns).  For
+// layers with few outputs (the 10-wide head) or shapes the fused kernel does not take.
+template <bool GBF, bool XBF>
+__global__ __launch_bounds__(256) void k_dgrad_plain(const void *__restrict__ gy, int64_t gy_sample_stride, int64_t ldgy,
+                                                     const float *__restrict__ w, int64_t w_sample_stride,
+                                                     void *__restrict__ gx, int64_t gx_sample_stride, int64_t ldgx,
+                                                     int M, int N, int K, int S)
+{
+    const int kq = (K + 3) / 4;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)S * M * kq) return;
+    const int c = (int)(id % kq);
+    const int m = (int)((id / kq) % M);
+    const int s = (int)(id / ((int64_t)kq * M));
+    const int k0 = 4 * c;
+    const float *ws = w + (int64_t)s * w_sample_stride;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+        float g;
+        if constexpr (GBF) g = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(gy)[(int64_t)s * gy_sample_stride + (int64_t)m * ldgy + n] << 16);
+        else g = reinterpret_cast<const float *>(gy)[(int64_t)s * gy_sample_stride + (int64_t)m * ldgy + n];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < K) acc[j] = fmaf(g, ws[(int64_t)n * K + k0 + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (k0 + j >= K) continue;
+        const int64_t o = (int64_t)s * gx_sample_stride + (int64_t)m * ldgx + k0 + j;
+        if constexpr (XBF) reinterpret_cast<uint16_t *>(gx)[o] = f2bf(acc[j]);
+        else reinterpret_cast<float *>(gx)[o] = acc[j];
+    }
+}
+
+// Vector form (K % 8 == 0, 16-B aligned w and gx): a thread owns 8 output columns of one row; the N
+// weights rows it needs are read as float4 pairs (shared by all rows of the batch through L1 / L2).
+template <bool GBF, bool XBF>
+__global__ __launch_bounds__(256) void k_dgrad_plain_v8(const void *__restrict__ gy, int64_t gy_sample_stride, int64_t ldgy,
+                                                        const float *__restrict__ w, int64_t w_sample_stride,
+                                                        void *__restrict__ gx, int64_t gx_sample_stride, int64_t ldgx,
+                                                        int M, int N, int K, int S)
+{
+    const int kq = K / 8;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)S * M * kq) return;
+    const int c = (int)(id % kq);
+    const int m = (int)((id / kq) % M);
+    const int s = (int)(id / ((int64_t)kq * M));
+    const float *ws = w + (int64_t)s * w_sample_stride + 8 * c;
+    const int64_t go = (int64_t)s * gy_sample_stride + (int64_t)m * ldgy;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+        float g;
+        if constexpr (GBF) g = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(gy)[go + n] << 16);
+        else g = reinterpret_cast<const float *>(gy)[go + n];
+        const float4 u = *reinterpret_cast<const float4 *>(ws + (int64_t)n * K);
+        const float4 v = *reinterpret_cast<const float4 *>(ws + (int64_t)n * K + 4);
+        acc[0] = fmaf(g, u.x, acc[0]); acc[1] = fmaf(g, u.y, acc[1]); acc[2] = fmaf(g, u.z, acc[2]); acc[3] = fmaf(g, u.w, acc[3]);
+        acc[4] = fmaf(g, v.x, acc[4]); acc[5] = fmaf(g, v.y, acc[5]); acc[6] = fmaf(g, v.z, acc[6]); acc[7] = fmaf(g, v.w, acc[7]);
+    }
+    const int64_t o = (int64_t)s * gx_sample_stride + (int64_t)m * ldgx + 8 * c;
+    if constexpr (XBF) {
+        uint4 h;
+        h.x = pack_bf16x2(acc[0], acc[1]); h.y = pack_bf16x2(acc[2], acc[3]);
+        h.z = pack_bf16x2(acc[4], acc[5]); h.w = pack_bf16x2(acc[6], acc[7]);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(gx) + o) = h;
+    } else {
+        float *q = reinterpret_cast<float *>(gx) + o;
+        *reinterpret_cast<float4 *>(q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(q + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+// ------------------------------------------------------------------ bias: column sums of gy per sample
+// out[s][n] = sum_m gy[s][m][n]; block = 64 columns x 4 row-slices, fixed-order LDS reduction.
+template <bool GBF>
+__global__ __launch_bounds__(256) void k_colsum(const void *__restrict__ gy, int64_t gy_sample_stride, int64_t ldgy,
+                                                float *__restrict__ out, int M, int N)
+{
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6, s = blockIdx.y;
+    float a = 0.f;
+    if (col < N) {
+        for (int m = part; m < M; m += 4) {
+            const int64_t o = (int64_t)s * gy_sample_stride + (int64_t)m * ldgy + col;
+            if constexpr (GBF) a += __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(gy)[o] << 16);
+            else a += reinterpret_cast<const float *>(gy)[o];
+        }
+    }
+    red[part][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (part == 0 && col < N) out[(int64_t)s * N + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// Vector form (N % 8 == 0, 16-B aligned rows): a thread owns 8 columns (one 16-B load per row for bf16,
+// two for fp32); block = 16 column groups x 16 row slices, fixed-order LDS reduction over the slices.
+template <bool GBF>
+__global__ __launch_bounds__(256) void k_colsum_v8(const void *__restrict__ gy, int64_t gy_sample_stride, int64_t ldgy,
+                                                   float *__restrict__ out, int M, int N)
+{
+    __shared__ float red[16][16][9];
+    const int cg = threadIdx.x & 15, part = threadIdx.x >> 4, s = blockIdx.y;
+    const int col = blockIdx.x * 128 + cg * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        for (int m = part; m < M; m += 16) {
+            const int64_t o = (int64_t)s * gy_sample_stride + (int64_t)m * ldgy + col;
+            if constexpr (GBF) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(gy) + o);
+                a[0] += __uint_as_float(v.x << 16); a[1] += __uint_as_float(v.x & 0xFFFF0000u);
+                a[2] += __uint_as_float(v.y << 16); a[3] += __uint_as_float(v.y & 0xFFFF0000u);
+                a[4] += __uint_as_float(v.z << 16); a[5] += __uint_as_float(v.z & 0xFFFF0000u);
+                a[6] += __uint_as_float(v.w << 16); a[7] += __uint_as_float(v.w & 0xFFFF0000u);
+            } else {
+                const float4 u = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(gy) + o);
+                const float4 w = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(gy) + o + 4);
+                a[0] += u.x; a[1] += u.y; a[2] += u.z; a[3] += u.w; a[4] += w.x; a[5] += w.y; a[6] += w.z; a[7] += w.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[part][cg][j] = a[j];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int n = blockIdx.x * 128 + c * 8 + j;
+        if (n < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += red[q][c][j];
+            out[(int64_t)s * N + n] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ ReLU mask: g * (y > 0)
+template <bool GBF, bool YBF>
+__global__ __launch_bounds__(256) void k_relu_bwd(const void *__restrict__ g, const void *__restrict__ y,
+                                                  void *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float yv;
+    if constexpr (YBF) yv = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(y)[i] << 16);
+    else yv = reinterpret_cast<const float *>(y)[i];
+    if constexpr (GBF) {
+        const uint16_t gv = reinterpret_cast<const uint16_t *>(g)[i];
+        reinterpret_cast<uint16_t *>(out)[i] = yv > 0.f ? gv : (uint16_t)0;
+    } else {
+        const float gv = reinterpret_cast<const float *>(g)[i];
+        reinterpret_cast<float *>(out)[i] = yv > 0.f ? gv : 0.f;
+    }
+}
+
+static inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+}  // namespace bnn
+
+using namespace bnn;
+
+extern "C" {
+
+int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
+                                       const void *gy, int64_t gy_sample_stride, int64_t ldgy,
+                                       const float *rho_w, float *g_mu, float *g_rho, int64_t M, int64_t N,
+                                       int64_t K, int nsamples, const bnn_rng_t *rng_w, int compute,
+                                       int flags, int accumulate, void *stream)
+{
+    const char *who = "bnn_linear_backward_weight_sampled";
+    if (!x || !gy || !rho_w || !g_mu || !g_rho) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldgy < N) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || N * K > ((int64_t)1 << 34)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    if (K % 4 == 0 && (!al16(g_mu) || !al16(g_rho))) { set_error("%s: gradients must be 16-B aligned", who); return BNN_E_ALIGN; }
+    const bool xh = (flags & BNN_FLAG_X_BF16) != 0, gh = (flags & BNN_FLAG_Y_BF16) != 0;
+    if ((xh || gh) && compute != BNN_COMPUTE_BF16) { set_error("%s: bf16 operands need bf16 compute", who); return BNN_E_UNSUPPORTED; }
+    if (compute != BNN_COMPUTE_F32 && compute != BNN_COMPUTE_BF16) { set_error("%s: unknown compute mode %d", who, compute); return BNN_E_DTYPE; }
+    int rc = check_rng(rng_w, nsamples);
+    if (rc) { set_error("%s: bad rng_w", who); return rc; }
+    hipStream_t st = (hipStream_t)stream;
+    WgradParams p{};
+    p.x = x; p.x_sample_stride = x_sample_stride; p.ldx = ldx;
+    p.gy = gy; p.gy_sample_stride = gy_sample_stride; p.ldgy = ldgy;
+    p.rho = rho_w; p.g_mu = g_mu; p.g_rho = g_rho;
+    p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.accumulate = accumulate;
+    p.rng = make_rng(rng_w);
+    p.vecX = al16(x) && (xh ? (ldx % 8 == 0 && x_sample_stride % 8 == 0) : (ldx % 4 == 0 && x_sample_stride % 4 == 0));
+    p.vecG = al16(gy) && (gh ? (ldgy % 8 == 0 && gy_sample_stride % 8 == 0) : (ldgy % 4 == 0 && gy_sample_stride % 4 == 0));
+    p.ntk = (int32_t)((K + W_TK - 1) / W_TK);
+    const int64_t ntn = (N + W_TN - 1) / W_TN, tiles = p.ntk * ntn;
+    // few tiles (small N * K): split the MC samples over gridDim.y, partials through the workspace
+    p.nsplit = 1;
+    GemmParams ws{};
+    fill_workspace(ws);
+    if (M == 0) {
+        if (!accumulate) {
+            rc = (int)hipMemsetAsync(g_mu, 0, (size_t)(N * K) * 4, st);
+            if (!rc) rc = (int)hipMemsetAsync(g_rho, 0, (size_t)(N * K) * 4, st);
+            if (rc) { set_error("%s: hipMemsetAsync failed (%d)", who, rc); return rc; }
+        }
+        return BNN_OK;
+    }
+    if (tiles < 64 && nsamples > 1 && ws.ws_slabs) {
+        int ns = nsamples < 8 ? nsamples : 8;
+        while (ns > 1 && (int64_t)ns * 2 * N * K * 4 > ws.ws_slab_bytes) --ns;
+        p.nsplit = ns;
+    }
+    if (p.nsplit > 1) {
+        p.slab_stride = 2 * N * K;
+        p.g_mu = ws.ws_slabs;
+        p.g_rho = nullptr;
+    }
+    const dim3 grid((unsigned)tiles, (unsigned)p.nsplit);
+    const bool dma_ok = p.vecX && p.vecG && M % W_BM == 0 && K % 8 == 0 && N % 8 == 0;
+    if (compute == BNN_COMPUTE_F32) {
+        hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(W_NT), 0, st, p);
+    } else if (xh && gh && dma_ok) {
+        hipLaunchKernelGGL(k_wgrad_bf16_dma, grid, dim3(W_NT), 0, st, p);
+    } else if (xh && gh) {
+        hipLaunchKernelGGL((k_wgrad_bf16<true, true>), grid, dim3(W_NT), 0, st, p);
+    } else if (xh) {
+        hipLaunchKernelGGL((k_wgrad_bf16<true, false>), grid, dim3(W_NT), 0, st, p);
+    } else if (gh) {
+        hipLaunchKernelGGL((k_wgrad_bf16<false, true>), grid, dim3(W_NT), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((k_wgrad_bf16<false, false>), grid, dim3(W_NT), 0, st, p);
+    }
+    rc = check_launch(who);
+    if (rc || p.nsplit == 1) return rc;
+    const int64_t n = N * K;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws.ws_slabs, p.slab_stride,
+                       p.nsplit, rho_w, g_mu, g_rho, n, accumulate);
+    return check_launch(who);
+}
+
+int bnn_linear_backward_weight(const void *x, int64_t x_sample_stride, int64_t ldx, const void *gy,
+                               int64_t gy_sample_stride, int64_t ldgy, float *gw, int64_t gw_sample_stride,
+                               int64_t M, int64_t N, int64_t K, int nsamples, int compute, int flags,
+                               int accumulate, void *stream)
+{
+    const char *who = "bnn_linear_backward_weight";
+    if (!x || !gy || !gw) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (M < 0 || N < 1 || K < 1 || nsamples < 1 || nsamples > 65535 || ldx < K || ldgy < N || gw_sample_stride < N * K) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || N * K > ((int64_t)1 << 34)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    if (K % 4 == 0 && (!al16(gw) || gw_sample_stride % 4 != 0)) { set_error("%s: gw must be 16-B aligned", who); return BNN_E_ALIGN; }
+    const bool xh = (flags & BNN_FLAG_X_BF16) != 0, gh = (flags & BNN_FLAG_Y_BF16) != 0;
+    if ((xh || gh) && compute != BNN_COMPUTE_BF16) { set_error("%s: bf16 operands need bf16 compute", who); return BNN_E_UNSUPPORTED; }
+    if (compute != BNN_COMPUTE_F32 && compute != BNN_COMPUTE_BF16) { set_error("%s: unknown compute mode %d", who, compute); return BNN_E_DTYPE; }
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        if (!accumulate)
+            for (int s = 0; s < nsamples; ++s) {
+                const int rc = (int)hipMemsetAsync(gw + (int64_t)s * gw_sample_stride, 0, (size_t)(N * K) * 4, st);
+                if (rc) { set_error("%s: hipMemsetAsync failed (%d)", who, rc); return rc; }
+            }
+        return BNN_OK;
+    }
+    WgradParams p{};
+    p.x = x; p.x_sample_stride = x_sample_stride; p.ldx = ldx;
+    p.gy = gy; p.gy_sample_stride = gy_sample_stride; p.ldgy = ldgy;
+    p.g_mu = gw; p.slab_stride = gw_sample_stride; p.plain = 1; p.nsplit = nsamples;
+    p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.accumulate = accumulate;
+    p.vecX = al16(x) && (xh ? (ldx % 8 == 0 && x_sample_stride % 8 == 0) : (ldx % 4 == 0 && x_sample_stride % 4 == 0));
+    p.vecG = al16(gy) && (gh ? (ldgy % 8 == 0 && gy_sample_stride % 8 == 0) : (ldgy % 4 == 0 && gy_sample_stride % 4 == 0));
+    p.ntk = (int32_t)((K + W_TK - 1) / W_TK);
+    const dim3 grid((unsigned)(p.ntk * ((N + W_TN - 1) / W_TN)), (unsigned)nsamples);
+    if (compute == BNN_COMPUTE_F32) hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(W_NT), 0, st, p);
+    else if (xh && gh) hipLaunchKernelGGL((k_wgrad_bf16<true, true>), grid, dim3(W_NT), 0, st, p);
+    else if (xh) hipLaunchKernelGGL((k_wgrad_bf16<true, false>), grid, dim3(W_NT), 0, st, p);
+    else if (gh) hipLaunchKernelGGL((k_wgrad_bf16<false, true>), grid, dim3(W_NT), 0, st, p);
+    else hipLaunchKernelGGL((k_wgrad_bf16<false, false>), grid, dim3(W_NT), 0, st, p);
+    return check_launch(who);
+}
+
+int bnn_linear_backward_input(const void *gy, int64_t gy_sample_stride, int64_t ldgy, const float *w,
+                              int64_t w_sample_stride, void *gx, int64_t gx_sample_stride, int64_t ldgx,
+                              int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream)
+{
+    const char *who = "bnn_linear_backward_input";
+    if (!gy || !w || !gx) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldgy < N || ldgx < K) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    const int64_t threads = (int64_t)nsamples * M * ((K + 3) / 4);
+    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || threads > ((int64_t)1 << 38)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    if (M == 0) return BNN_OK;
+    const bool gh = (flags & BNN_FLAG_X_BF16) != 0, xh = (flags & BNN_FLAG_Y_BF16) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (K % 8 == 0 && al16(w) && w_sample_stride % 4 == 0 && al16(gx) && ldgx % 8 == 0 && gx_sample_stride % 8 == 0) {
+        const int64_t th8 = (int64_t)nsamples * M * (K / 8);
+        const dim3 g8((unsigned)((th8 + 255) / 256));
+#define BNN_DGRAD8(G, X) hipLaunchKernelGGL((k_dgrad_plain_v8<G, X>), g8, dim3(256), 0, st, gy, gy_sample_stride, ldgy, w, \
+                                            w_sample_stride, gx, gx_sample_stride, ldgx, (int)M, (int)N, (int)K, nsamples)
+        if (gh && xh) BNN_DGRAD8(true, true);
+        else if (gh) BNN_DGRAD8(true, false);
+        else if (xh) BNN_DGRAD8(false, true);
+        else BNN_DGRAD8(false, false);
+#undef BNN_DGRAD8
+        return check_launch(who);
+    }
+    const dim3 grid((unsigned)((threads + 255) / 256));
+#define BNN_DGRAD(G, X) hipLaunchKernelGGL((k_dgrad_plain<G, X>), grid, dim3(256), 0, st, gy, gy_sample_stride, ldgy, w, \
+                                           w_sample_stride, gx, gx_sample_stride, ldgx, (int)M, (int)N, (int)K, nsamples)
+    if (gh && xh) BNN_DGRAD(true, true);
+    else if (gh) BNN_DGRAD(true, false);
+    else if (xh) BNN_DGRAD(false, true);
+    else BNN_DGRAD(false, false);
+#undef BNN_DGRAD
+    return check_launch(who);
+}
+
+int bnn_colsum(const void *gy, int64_t gy_sample_stride, int64_t ldgy, float *out, int64_t M, int64_t N,
+               int nsamples, int flags, void *stream)
+{
+    const char *who = "bnn_colsum";
+    if (!gy || !out) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (M < 0 || N < 1 || nsamples < 1 || ldgy < N) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || nsamples > 65535) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    const bool gh = (flags & BNN_FLAG_X_BF16) != 0;
+    if (N % 8 == 0 && ldgy % 8 == 0 && gy_sample_stride % 8 == 0 && al16(gy)) {
+        const dim3 g8((unsigned)((N + 127) / 128), (unsigned)nsamples);
+        if (gh) hipLaunchKernelGGL((k_colsum_v8<true>), g8, dim3(256), 0, (hipStream_t)stream, gy, gy_sample_stride, ldgy, out, (int)M, (int)N);
+        else hipLaunchKernelGGL((k_colsum_v8<false>), g8, dim3(256), 0, (hipStream_t)stream, gy, gy_sample_stride, ldgy, out, (int)M, (int)N);
+        return check_launch(who);
+    }
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)nsamples);
+    if (gh) hipLaunchKernelGGL((k_colsum<true>), grid, dim3(256), 0, (hipStream_t)stream, gy, gy_sample_stride, ldgy, out, (int)M, (int)N);
+    else hipLaunchKernelGGL((k_colsum<false>), grid, dim3(256), 0, (hipStream_t)stream, gy, gy_sample_stride, ldgy, out, (int)M, (int)N);
+    return check_launch(who);
+}
+
+int bnn_relu_backward(const void *g, const void *y, void *out, int64_t n, int flags, void *stream)
+{
+    const char *who = "bnn_relu_backward";
+    if (!g || !y || !out) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (n < 0 || n > ((int64_t)1 << 38)) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (n == 0) return BNN_OK;
+    const bool gh = (flags & BNN_FLAG_X_BF16) != 0, yh = (flags & BNN_FLAG_Y_BF16) != 0;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (gh && yh) hipLaunchKernelGGL((k_relu_bwd<true, true>), grid, dim3(256), 0, st, g, y, out, n);
+    else if (gh) hipLaunchKernelGGL((k_relu_bwd<true, false>), grid, dim3(256), 0, st, g, y, out, n);
+    else if (yh) hipLaunchKernelGGL((k_relu_bwd<false, true>), grid, dim3(256), 0, st, g, y, out, n);
+    else hipLaunchKernelGGL((k_relu_bwd<false, false>), grid, dim3(256), 0, st, g, y, out, n);
+    return check_launch(who);
+}
+
+}  // extern "C"

@@ -147,8 +147,53 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
     return y
 
 
+def _bf(t):
+    return t.dtype == torch.bfloat16
+
+
+def _relu_backward_raw(g, y):
+    """g * (y > 0) (the fused ReLU epilogue's backward)."""
+    out = torch.empty_like(g)
+    flags = (_lib.FLAG_X_BF16 if _bf(g) else 0) | (_lib.FLAG_Y_BF16 if _bf(y) else 0)
+    check(_lib.load().bnn_relu_backward(ptr(g), ptr(y), ptr(out), g.numel(), flags, stream_ptr(g.device)),
+          "bnn_relu_backward")
+    return out
+
+
+def _colsum_raw(gy):
+    """(S, M, N) -> (S, N) fp32 column sums (the bias gradient of F.linear)."""
+    S, M, N = gy.shape
+    out = torch.empty((S, N), dtype=torch.float32, device=gy.device)
+    check(_lib.load().bnn_colsum(ptr(gy), M * N, N, ptr(out), M, N, S, _lib.FLAG_X_BF16 if _bf(gy) else 0,
+                                 stream_ptr(gy.device)), "bnn_colsum")
+    return out
+
+
+def _dgrad_plain_raw(gy, w, x_dtype):
+    """gx[s] = gy[s] @ w[s] with explicit fp32 weights (S, N, K)."""
+    S, M, N = gy.shape
+    K = w.shape[2]
+    gx = torch.empty((S, M, K), dtype=x_dtype, device=gy.device)
+    flags = (_lib.FLAG_X_BF16 if _bf(gy) else 0) | (_lib.FLAG_Y_BF16 if x_dtype == torch.bfloat16 else 0)
+    check(_lib.load().bnn_linear_backward_input(ptr(gy), M * N, N, ptr(w), N * K, ptr(gx), M * K, K, M, N, K, S,
+                                                flags, stream_ptr(gy.device)), "bnn_linear_backward_input")
+    return gx
+
+
+def _sum_samples(t):
+    """(S, ...) fp32 -> sum over S (bnn_mc_sum, scale 1)."""
+    out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
+    n = out.numel()
+    check(_lib.load().bnn_mc_sum(ptr(t), n, t.shape[0], n, 1.0, ptr(out), 0, None, 0, stream_ptr(t.device)),
+          "bnn_mc_sum")
+    return out
+
+
 class _SampledLinear(torch.autograd.Function):
-    """y[s] = x[s] @ w_s^T + b_s, w_s / b_s drawn in-kernel (NormalLinear.forward, dense.py:56-60)."""
+    """y[s] = x[s] @ w_s^T + b_s, w_s / b_s drawn in-kernel (NormalLinear.forward, dense.py:56-60).
+    Backward (what autograd derives in the reference, train.py:63-65) is HIP as well: the input
+    gradient re-draws w_s inside the contraction, the weight gradient folds the draw's backward
+    into its epilogue (csrc/bnn_linear_bwd.hip)."""
 
     @staticmethod
     def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute, relu, out_dtype):
@@ -169,31 +214,52 @@ class _SampledLinear(torch.autograd.Function):
         y = _linear_sampled_raw(x, 0 if shared_x else M * K, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b,
                                 compute, relu, out_dtype)
         ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None, y if relu else None)
-        ctx.key_w, ctx.key_b, ctx.shared_x = key_w, key_b, shared_x
+        ctx.key_w, ctx.key_b, ctx.shared_x, ctx.compute = key_w, key_b, shared_x, compute
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, mu_w, rho_w, rho_b, y_relu = ctx.saved_tensors
-        S = ctx.key_w.nsamples
-        x_dtype = x.dtype
-        x = x.float()
-        gy = gy.float().contiguous()
+        S, compute = ctx.key_w.nsamples, ctx.compute
+        N, K = mu_w.shape
+        M = x.shape[-2]
+        dev = gy.device
+        lib = _lib.load()
+        _lib.ensure_workspace(dev)
+        gy = gy.contiguous()
+        if compute != _lib.COMPUTE_BF16 and gy.dtype != torch.float32:
+            gy = gy.float()
         if y_relu is not None:
-            gy = gy * (y_relu > 0).to(gy.dtype)                            # fused ReLU
+            gy = _relu_backward_raw(gy, y_relu)                            # fused ReLU
+        gflag = _lib.FLAG_X_BF16 if _bf(gy) else 0
+        rw = _rng_struct(ctx.key_w, dev)
         gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
         if ctx.needs_input_grad[0]:
-            w = _sample_affine_philox_raw(mu_w, rho_w, ctx.key_w)          # (S, N, K), HIP
-            gx = torch.bmm(gy, w)                                          # (S, M, K)
+            # a shared input sums its gradient over the samples: fp32 partials, then one reduction
+            gx_dtype = torch.float32 if ctx.shared_x else x.dtype
+            fused = K % 4 == 0 and N % (8 if _bf(gy) else 4) == 0 and \
+                (compute == _lib.COMPUTE_BF16 or (not _bf(gy) and gx_dtype == torch.float32))
+            if fused:
+                gx = torch.empty((S, M, K), dtype=gx_dtype, device=dev)
+                flags = gflag | (_lib.FLAG_Y_BF16 if gx_dtype == torch.bfloat16 else 0)
+                check(lib.bnn_linear_backward_input_sampled(ptr(gy), M * N, N, ptr(mu_w), ptr(rho_w), ptr(gx),
+                                                            M * K, K, M, N, K, S, ctypes.byref(rw), compute, flags,
+                                                            stream_ptr(dev)), "bnn_linear_backward_input_sampled")
+            else:
+                w = _sample_affine_philox_raw(mu_w, rho_w, ctx.key_w)      # (S, N, K) fp32, the forward's draw
+                gx = _dgrad_plain_raw(gy, w, gx_dtype)
             if ctx.shared_x:
-                gx = gx.sum(0)
-            gx = gx.to(x_dtype)
+                gx = _sum_samples(gx).to(x.dtype)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            xs = x.unsqueeze(0).expand(S, -1, -1) if ctx.shared_x else x
-            gw = torch.bmm(gy.transpose(1, 2), xs)                         # (S, N, K)
-            g_mu_w, g_rho_w = _sample_affine_bwd_raw(gw, rho_w, rho_w.numel(), S, key=ctx.key_w)
+            g_mu_w = torch.empty_like(mu_w)
+            g_rho_w = torch.empty_like(rho_w)
+            flags = (_lib.FLAG_X_BF16 if _bf(x) else 0) | (_lib.FLAG_Y_BF16 if _bf(gy) else 0)
+            check(lib.bnn_linear_backward_weight_sampled(ptr(x), 0 if ctx.shared_x else M * K, K, ptr(gy), M * N, N,
+                                                         ptr(rho_w), ptr(g_mu_w), ptr(g_rho_w), M, N, K, S,
+                                                         ctypes.byref(rw), compute, flags, 0, stream_ptr(dev)),
+                  "bnn_linear_backward_weight_sampled")
         if rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
-            gb = gy.sum(1)                                                 # (S, N)
+            gb = _colsum_raw(gy)                                           # (S, N)
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
         return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None
 
@@ -224,24 +290,27 @@ class _PlainLinear(torch.autograd.Function):
                                               ptr(y), M * N, N, M, N, K, S, compute, 0, stream_ptr(x.device)),
               "bnn_linear_forward")
         ctx.save_for_backward(x, w)
-        ctx.shared_x, ctx.has_b = shared_x, b is not None
+        ctx.shared_x, ctx.has_b, ctx.compute = shared_x, b is not None, compute
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        S = w.shape[0]
+        S, N, K = w.shape
+        M = x.shape[-2]
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.bmm(gy, w)
+            gx = _dgrad_plain_raw(gy, w, torch.float32)
             if ctx.shared_x:
-                gx = gx.sum(0)
+                gx = _sum_samples(gx)
         if ctx.needs_input_grad[1]:
-            xs = x.unsqueeze(0).expand(S, -1, -1) if ctx.shared_x else x
-            gw = torch.bmm(gy.transpose(1, 2), xs)
+            gw = torch.empty_like(w)
+            check(_lib.load().bnn_linear_backward_weight(ptr(x), 0 if ctx.shared_x else M * K, K, ptr(gy), M * N, N,
+                                                         ptr(gw), N * K, M, N, K, S, ctx.compute, 0, 0,
+                                                         stream_ptr(gy.device)), "bnn_linear_backward_weight")
         if ctx.has_b and ctx.needs_input_grad[2]:
-            gb = gy.sum(1)
+            gb = _colsum_raw(gy)
         return gx, gw, gb, None, None
 
 

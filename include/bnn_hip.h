@@ -182,6 +182,55 @@ int bnn_linear_forward(const float *x, int64_t x_sample_stride, int64_t ldx,
                        int64_t M, int64_t N, int64_t K, int nsamples,
                        int compute, int flags, void *stream);
 
+/* ---- backward of K2 linear -----------------------------------
+ * replaces  what autograd derives from F.linear(x, w, b) (dense.py:60) and
+ *           w = mu + sigma(rho) * eps (core.py:44-45) in loss.backward()
+ *           (examples/MNIST/train.py:63-65).  W is (N, K) row-major, as in the forward.
+ *
+ * Input gradient, fused with the re-creation of the forward's draw (same rng_w key):
+ *     gx[s][m][k] = sum_n gy[s][m][n] * W_s[n][k],   W_s = mu_w + sigma(rho_w) * eps_s
+ * flags: BNN_FLAG_X_BF16 = gy is bf16, BNN_FLAG_Y_BF16 = gx is written as bf16 (bf16 compute only).
+ * Needs K % 4 == 0, N % 4 == 0 (fp32 gy) / N % 8 == 0 (bf16 gy), 16-B aligned operands;
+ * returns BNN_E_UNSUPPORTED otherwise (callers then draw W_s with bnn_sample_affine_philox and
+ * use bnn_linear_backward_input). */
+int bnn_linear_backward_input_sampled(const void *gy, int64_t gy_sample_stride, int64_t ldgy,
+                                      const float *mu_w, const float *rho_w,
+                                      void *gx, int64_t gx_sample_stride, int64_t ldgx,
+                                      int64_t M, int64_t N, int64_t K, int nsamples,
+                                      const bnn_rng_t *rng_w, int compute, int flags, void *stream);
+/* Same with the weights given: w[s] = w + s * w_sample_stride, fp32 (any shape). */
+int bnn_linear_backward_input(const void *gy, int64_t gy_sample_stride, int64_t ldgy,
+                              const float *w, int64_t w_sample_stride,
+                              void *gx, int64_t gx_sample_stride, int64_t ldgx,
+                              int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream);
+/* Weight gradient fused with the backward of the draw (dW_s = gy_s^T x_s is never stored):
+ *     g_mu [n][k] (+)= sum_s dW_s[n][k]
+ *     g_rho[n][k] (+)= sum_s dW_s[n][k] * eps_s[n][k] * sigmoid(rho_w[n][k])
+ * x: (S, M, K) or shared (x_sample_stride = 0).  flags: BNN_FLAG_X_BF16 = x is bf16,
+ * BNN_FLAG_Y_BF16 = gy is bf16 (bf16 compute only).  With few output tiles
+ * the MC samples are split over workgroups through the registered workspace and added in a fixed
+ * order: bitwise reproducible. */
+int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
+                                       const void *gy, int64_t gy_sample_stride, int64_t ldgy,
+                                       const float *rho_w, float *g_mu, float *g_rho,
+                                       int64_t M, int64_t N, int64_t K, int nsamples,
+                                       const bnn_rng_t *rng_w, int compute, int flags,
+                                       int accumulate, void *stream);
+/* F.linear's own weight gradient, per sample: gw[s][n][k] (+)= sum_m gy[s][m][n] * x[s][m][k],
+ * gw[s] = gw + s * gw_sample_stride (parity mode, where the draw is a separate op). */
+int bnn_linear_backward_weight(const void *x, int64_t x_sample_stride, int64_t ldx,
+                               const void *gy, int64_t gy_sample_stride, int64_t ldgy,
+                               float *gw, int64_t gw_sample_stride,
+                               int64_t M, int64_t N, int64_t K, int nsamples,
+                               int compute, int flags, int accumulate, void *stream);
+/* Bias: out[s][n] = sum_m gy[s][m][n]  (feed out to bnn_sample_affine_bwd with the bias key).
+ * flags: BNN_FLAG_X_BF16 = gy is bf16. */
+int bnn_colsum(const void *gy, int64_t gy_sample_stride, int64_t ldgy, float *out,
+               int64_t M, int64_t N, int nsamples, int flags, void *stream);
+/* Fused-ReLU layers: out[i] = y[i] > 0 ? g[i] : 0.  flags: BNN_FLAG_X_BF16 = g and out are bf16,
+ * BNN_FLAG_Y_BF16 = y is bf16. */
+int bnn_relu_backward(const void *g, const void *y, void *out, int64_t n, int flags, void *stream);
+
 /* ---- K2: sampled conv2d (implicit GEMM) --------------------------------------
  * replaces  NormalConv2d.forward   pytorch_bayesian/nn/conv.py:112-119
  *   y[s] = conv2d(x[s], w_s, b_s, stride, padding, dilation, groups), NCHW / OIHW.

@@ -582,6 +582,158 @@ def test_training_step_gradients_match_oracle(env):
     assert np.allclose(N(L1.bias.scale.grad), g_rho_b1 + kr, rtol=1e-4, atol=1e-4)
 
 
+# ------------------------------------------------------------------ backward kernels
+def _bwd_case(env, S, M, N, K, seed, shared_x=False):
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    gen = torch.Generator().manual_seed(seed)
+    mu = torch.randn(N, K, generator=gen) * 0.1
+    rho = torch.randn(N, K, generator=gen) * 0.15 - 2.0
+    x = torch.randn((M, K) if shared_x else (S, M, K), generator=gen)
+    gy = torch.randn(S, M, N, generator=gen)
+    key = DrawKey(99 + seed, 21, 0, S, 7)
+    orc = env["orc"]
+    eps = [orc.eps_fill(key.seed, key.stream, s, key.epoch_host, 0, (N, K)) for s in range(S)]
+    return mu, rho, x, gy, key, eps
+
+
+def _oracle_linear_bwd(orc, mu, rho, x, gy, eps, shared_x, rounder=lambda a: a):
+    """float64 restatement of autograd through F.linear (dense.py:60) and mu + sigma * eps (core.py:45)."""
+    S = gy.shape[0]
+    g_mu = np.zeros(mu.shape, np.float64)
+    g_rho = np.zeros(mu.shape, np.float64)
+    gx = []
+    for s in range(S):
+        xs = rounder(N(x if shared_x else x[s])).astype(np.float64)
+        g = rounder(N(gy[s])).astype(np.float64)
+        w = rounder(orc.sample_affine(N(mu), N(rho), eps[s])).astype(np.float64)
+        gw = g.T @ xs
+        a, b = orc.sample_affine_bwd(np.ones(mu.shape, np.float32), N(rho), eps[s])   # d w / d mu, d w / d rho
+        g_mu += gw * a
+        g_rho += gw * b
+        gx.append(g @ w)
+    return g_mu, g_rho, np.stack(gx)
+
+
+BWD_SHAPES = [(1, 1, 1, 4), (2, 9, 6, 24), (3, 33, 10, 1200), (2, 70, 130, 260), (8, 64, 48, 136),
+              (2, 5, 7, 11), (1, 40, 3, 9)]
+
+
+@pytest.mark.parametrize("S,M,Nn,K", BWD_SHAPES)
+@pytest.mark.parametrize("shared_x", [False, True])
+def test_weight_gradient_kernel_vs_oracle_f32(env, S, M, Nn, K, shared_x):
+    """bnn_linear_backward_weight_sampled, exact fp32: g_mu / g_rho vs the oracle on the same draws
+    (ragged tiles, odd K, sample split through the workspace for small outputs)."""
+    mu, rho, x, gy, key, eps = _bwd_case(env, S, M, Nn, K, 1, shared_x)
+    dev = env["dev"]
+    xd = x.to(dev)
+    mud, rhod = mu.to(dev).requires_grad_(True), rho.to(dev).requires_grad_(True)
+    y = env["ops"].linear_sampled(xd, mud, rhod, None, None, key, None, shared_x)
+    g_mu, g_rho = torch.autograd.grad(y, (mud, rhod), gy.to(dev))
+    want_mu, want_rho, _ = _oracle_linear_bwd(env["orc"], mu, rho, x, gy, eps, shared_x)
+    assert allclose_scaled(N(g_mu), want_mu)
+    assert allclose_scaled(N(g_rho), want_rho)
+
+
+@pytest.mark.parametrize("S,M,Nn,K", BWD_SHAPES)
+def test_input_gradient_kernel_vs_oracle_f32(env, S, M, Nn, K):
+    """bnn_linear_backward_input_sampled (fused re-draw, aligned shapes) / bnn_linear_backward_input
+    (explicit weights, the rest): gx vs the oracle, per sample and summed for a shared input."""
+    for shared_x in (False, True):
+        mu, rho, x, gy, key, eps = _bwd_case(env, S, M, Nn, K, 2, shared_x)
+        dev = env["dev"]
+        xd = x.to(dev).requires_grad_(True)
+        y = env["ops"].linear_sampled(xd, mu.to(dev), rho.to(dev), None, None, key, None, shared_x)
+        (gx,) = torch.autograd.grad(y, (xd,), gy.to(dev))
+        _, _, want = _oracle_linear_bwd(env["orc"], mu, rho, x, gy, eps, shared_x)
+        if shared_x:
+            want = want.sum(0)
+        assert allclose_scaled(N(gx), want)
+
+
+@pytest.mark.parametrize("S,M,Nn,K", [(2, 9, 8, 24), (3, 33, 16, 1200), (8, 64, 48, 136), (2, 70, 136, 264)])
+def test_backward_kernels_bf16_mode(env, S, M, Nn, K):
+    """bf16 operands (x, gy and the re-drawn W rounded to bf16), fp32 accumulate; transposed LDS reads
+    in the weight gradient.  Checked against the oracle fed the same bf16-rounded operands: 2e-3 of the
+    output scale (fp32 accumulation order only), and against the exact gradient at 2e-2."""
+    orc = env["orc"]
+    dev = env["dev"]
+    mu, rho, x, gy, key, eps = _bwd_case(env, S, M, Nn, K, 3)
+    for act_dtype in (torch.float32, torch.bfloat16):
+        xd = x.to(dev).to(act_dtype).requires_grad_(True)
+        mud, rhod = mu.to(dev).requires_grad_(True), rho.to(dev).requires_grad_(True)
+        y = env["ops"].linear_sampled(xd, mud, rhod, None, None, key, None, False, compute="bf16", out_dtype=act_dtype)
+        gx, g_mu, g_rho = torch.autograd.grad(y, (xd, mud, rhod), gy.to(dev).to(act_dtype))
+        want_mu, want_rho, want_x = _oracle_linear_bwd(orc, mu, rho, x, gy, eps, False, rounder=orc.bf16_round)
+        exact_mu, exact_rho, exact_x = _oracle_linear_bwd(orc, mu, rho, x, gy, eps, False)
+        assert allclose_scaled(N(g_mu), want_mu, 2e-3)
+        assert allclose_scaled(N(g_rho), want_rho, 2e-3)
+        assert allclose_scaled(N(gx.float()), want_x, 2e-3 if act_dtype == torch.float32 else 1e-2)
+        assert allclose_scaled(N(g_mu), exact_mu, 2e-2) and allclose_scaled(N(gx.float()), exact_x, 2e-2)
+
+
+def test_bias_colsum_and_relu_mask_kernels(env):
+    dev = env["dev"]
+    gy = torch.randn(3, 37, 130, device=dev)
+    out = env["ops"]._colsum_raw(gy)
+    assert allclose_scaled(N(out), N(gy).astype(np.float64).sum(1))
+    outh = env["ops"]._colsum_raw(gy.bfloat16())
+    assert allclose_scaled(N(outh), N(gy.bfloat16().float()).astype(np.float64).sum(1))
+    y = torch.randn(3, 37, 130, device=dev)
+    for gd in (torch.float32, torch.bfloat16):
+        for yd in (torch.float32, torch.bfloat16):
+            m = env["ops"]._relu_backward_raw(gy.to(gd), y.to(yd))
+            assert torch.equal(m, gy.to(gd) * (y.to(yd) > 0).to(gd))
+
+
+def test_weight_gradient_is_bitwise_reproducible_and_accumulates(env):
+    """Fixed-order reductions (incl. the split over samples): two runs agree bit for bit; accumulate adds."""
+    from bayesianneuralnetworks_amd import _lib
+    from bayesianneuralnetworks_amd.ops import _rng_struct
+    import ctypes
+    dev = env["dev"]
+    for (S, M, Nn, K) in ((8, 64, 10, 1200), (2, 100, 200, 264)):
+        mu, rho, x, gy, key, eps = _bwd_case(env, S, M, Nn, K, 4)
+        xd, gyd, rhod = x.to(dev), gy.to(dev), rho.to(dev)
+        _lib.ensure_workspace(dev)
+        r = _rng_struct(key, dev)
+        outs = []
+        for acc in (0, 0, 1):
+            gm = torch.full((Nn, K), 1.0, device=dev)
+            gr = torch.full((Nn, K), 2.0, device=dev)
+            _lib.check(env["lib"].bnn_linear_backward_weight_sampled(
+                _lib.ptr(xd), M * K, K, _lib.ptr(gyd), M * Nn, Nn, _lib.ptr(rhod), _lib.ptr(gm), _lib.ptr(gr),
+                M, Nn, K, S, ctypes.byref(r), _lib.COMPUTE_F32, 0, acc, _lib.stream_ptr(dev)), "wgrad")
+            outs.append((gm, gr))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert torch.allclose(outs[2][0], outs[0][0] + 1.0, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(outs[2][1], outs[0][1] + 2.0, rtol=1e-6, atol=1e-6)
+
+
+def test_full_size_backward_properties(env):
+    """BASELINE layer (8 x 512 x 1200 x 1200, bf16 activations): the weight gradient is linear in gy and
+    the input gradient of a frozen draw is linear in gy (size-independent properties)."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    dev = env["dev"]
+    gen = torch.Generator().manual_seed(11)
+    mu = (torch.randn(1200, 1200, generator=gen) * 0.03).to(dev).requires_grad_(True)
+    rho = (torch.randn(1200, 1200, generator=gen) * 0.15 - 2).to(dev).requires_grad_(True)
+    x = torch.randn(8, 512, 1200, generator=gen).to(dev).bfloat16().requires_grad_(True)
+    g1 = torch.randn(8, 512, 1200, generator=gen).to(dev).bfloat16()
+    g2 = torch.randn(8, 512, 1200, generator=gen).to(dev).bfloat16()
+    key = DrawKey(5, 3, 0, 8, 1)
+    y = env["ops"].linear_sampled(x, mu, rho, None, None, key, None, False, compute="bf16", out_dtype=torch.bfloat16)
+    ga = torch.autograd.grad(y, (x, mu, rho), g1, retain_graph=True)
+    gb = torch.autograd.grad(y, (x, mu, rho), g2, retain_graph=True)
+    gs = torch.autograd.grad(y, (x, mu, rho), (g1.float() + g2.float()).bfloat16())
+    # g1 + g2 and the bf16 outputs are each rounded once more (2^-9 relative per element): compare
+    # in the Frobenius norm at the bf16 bar, and element-wise at 5 % of the output scale
+    for a, b, c in zip(ga, gb, gs):
+        want = a.float() + b.float()
+        assert float((c.float() - want).norm() / want.norm()) < 5e-3
+        assert allclose_scaled(N(c.float()), N(want), 5e-2)
+    assert all(torch.isfinite(t.float()).all() for t in gs)
+
+
 # ------------------------------------------------------------------ properties at full size
 def test_full_size_linearity_property(env):
     """BASELINE size (512 x 1200 x 1200): with the draw frozen (sample=False) and no bias the
