@@ -45,6 +45,24 @@ __device__ __forceinline__ void dma16xN(const char *const (&src)[PW], int byte_o
     }
 }
 
+// Three pieces, scalar-base form: piece i comes from (base_i + voff_i) -- a 64-bit wave-uniform base in
+// SGPRs plus a 32-bit per-lane byte offset -- and lands at lds_i + 16 * lane.  No VALU address math per
+// issue: the bases advance with scalar adds, the lane offsets are fixed for the life of the kernel.
+__device__ __forceinline__ void dma16_s3(const void *base0, uint32_t voff0, uint32_t lds0,
+                                         const void *base1, uint32_t voff1, uint32_t lds1,
+                                         const void *base2, uint32_t voff2, uint32_t lds2)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %8\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff0), "s"(base0), "s"(lds0), "v"(voff1), "s"(base1), "s"(lds1), "v"(voff2), "s"(base2), "s"(lds2)
+                 : "memory");
+}
+
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;

@@ -19,6 +19,9 @@
 //         plain ds_read_b32 (rows padded by 16 floats: the four m of a step sit on disjoint banks).
 // Small outputs (N * K small, e.g. the 10-wide head) split the MC samples over gridDim.y; the
 // partials go to the registered workspace and a second kernel adds them in a fixed order.
+#include <cstdlib>
+#include <type_traits>
+
 #include "bnn_device.hpp"
 #include "bnn_gemm_params.hpp"
 #include "bnn_dma.hpp"
@@ -38,7 +41,7 @@ struct WgradParams {
     const float *rho;           // (N, K)
     float *g_mu, *g_rho;        // (N, K), or the workspace slabs when nsplit > 1
     int64_t slab_stride;        // floats between the partials of two sample groups (nsplit > 1)
-    int32_t M, N, K, S, accumulate, ntk, nsplit;
+    int32_t M, N, K, S, accumulate, ntk, ntn, nsplit;
     int32_t vecX, vecG;         // 16-B loads legal
     int32_t plain;              // 1: no draw -- out[s] = dW_s per sample (gridDim.y = S), F.linear's own gradient
     RngDev rng;
@@ -104,16 +107,55 @@ __device__ __forceinline__ float4 load4_f32(const float *base, int64_t row_off, 
     return o;
 }
 
+// Tile decode, XCD-aware: workgroup L runs on XCD L % 8 (round-robin dispatch); the 8 XCDs form a 2 (k) x 4 (n)
+// grid over the tile grid, so one XCD's L2 holds half of x's column panels and a quarter of gy's instead of
+// all of both.  gridDim.x = 8 * sub_k * sub_n; workgroups that fall outside the tile grid exit at once.
+__device__ __forceinline__ bool wgrad_tile(const WgradParams &p, int &kt, int &nt)
+{
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int sub_k = (p.ntk + 1) / 2, sub_n = (p.ntn + 3) / 4;
+    kt = (xcd & 1) * sub_k + idx % sub_k;
+    nt = (xcd >> 1) * sub_n + idx / sub_k;
+    return idx < sub_k * sub_n && kt < p.ntk && nt < p.ntn;
+}
+
 // Shared tail of both kernels.  Accumulator element acc[a][b][r] is output (n, k):
 //   n = n0 + wn * 32 + b * 16 + (lane & 15),  k = k0 + wk * 64 + a * 16 + 4 * (lane >> 4) + r.
 struct WgradAcc {
     f32x4 acc[4][2], gmu[4][2], grho[4][2];
 };
 
+// UNCOND: draw eps for every accumulator tile, in range or not (out-of-range outputs are discarded by
+// wgrad_store) -- one straight-line block, so the independent Philox chains of the 8 tiles interleave.
+template <bool UNCOND = false>
 __device__ __forceinline__ void wgrad_sample_end(WgradAcc &A, const WgradParams &p, uint32_t edev, int s, int nb, int kb)
 {
     const int lane = threadIdx.x & 63;
     const bool k4 = (p.K & 3) == 0;              // rows start on a Philox block: one block per 4 outputs
+    if constexpr (UNCOND) {                      // (needs K % 4 == 0)
+        if (!p.plain) {
+            const uint32_t sample = p.rng.sample0 + (uint32_t)s;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int n = nb + b * 16 + (lane & 15), k = kb + a * 16 + 4 * (lane >> 4);
+                    const float4 z = eps4(p.rng, edev, (uint32_t)(((int64_t)n * p.K + k) >> 2), sample);
+                    A.grho[a][b][0] = fmaf(A.acc[a][b][0], z.x, A.grho[a][b][0]);
+                    A.grho[a][b][1] = fmaf(A.acc[a][b][1], z.y, A.grho[a][b][1]);
+                    A.grho[a][b][2] = fmaf(A.acc[a][b][2], z.z, A.grho[a][b][2]);
+                    A.grho[a][b][3] = fmaf(A.acc[a][b][3], z.w, A.grho[a][b][3]);
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                A.gmu[a][b] += A.acc[a][b];
+                A.acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -140,7 +182,6 @@ __device__ __forceinline__ void wgrad_sample_end(WgradAcc &A, const WgradParams 
                 }
             }
             A.acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_sched_barrier(0);   // one Philox block at a time: 8 interleaved ones spill
         }
 }
 
@@ -189,13 +230,14 @@ __device__ __forceinline__ void wgrad_store(const WgradAcc &A, const WgradParams
 
 // ------------------------------------------------------------------ bf16 operands, fp32 accumulate
 template <bool XBF, bool GBF>
-__global__ __launch_bounds__(W_NT, 2) void k_wgrad_bf16(const WgradParams p)
+__global__ __launch_bounds__(W_NT) void k_wgrad_bf16(const WgradParams p)
 {
     constexpr int XB = W_BM * W_TK * 2, GB = W_BM * W_TN * 2;     // 8 KB + 4 KB per buffer
     __shared__ __attribute__((aligned(16))) char lds[2 * (XB + GB)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave >> 1, wn = wave & 1;                       // 2 x 2 waves, 64 k x 32 n each
-    const int kt = blockIdx.x % p.ntk, nt = blockIdx.x / p.ntk;
+    int kt, nt;
+    if (!wgrad_tile(p, kt, nt)) return;
     const int k0 = kt * W_TK, n0 = nt * W_TN;
     const int s_lo = (int)((int64_t)blockIdx.y * p.S / p.nsplit), s_hi = (int)((int64_t)(blockIdx.y + 1) * p.S / p.nsplit);
     const int msteps = (p.M + W_BM - 1) / W_BM;
@@ -274,27 +316,32 @@ __global__ __launch_bounds__(W_NT, 2) void k_wgrad_bf16(const WgradParams p)
     wgrad_store(A, p, nb, kb);
 }
 
-// Same contraction for the hot case -- x and gy both bf16 in memory, M % 32 == 0, K % 8 == 0, N % 8 == 0:
+// Same contraction for the hot case -- x and gy both bf16 in memory, M % 256 == 0, K % 8 == 0, N % 8 == 0:
 // the [32 m][cols] images ARE the memory layout, so LDS-DMA (global_load_lds_dwordx4) fills them
 // without touching registers, the XOR swizzle applied on the source side (lane l of a 1-KiB piece
-// fetches the chunk that belongs in LDS slot l).  4-deep ring, three steps in flight per wave, one
-// barrier per step; wave w owns X pieces 2w, 2w+1 and G piece w of every step (rows 8w .. 8w+7).
+// fetches the chunk that belongs in LDS slot l).  Ring of 8 images (96 KB) handled in pairs: one barrier per
+// 64 rows, three pairs in flight per wave; wave w owns X pieces 2w, 2w+1 and G piece w of every step (rows 8w .. 8w+7).
+// The loop is instruction-bound (one wave per SIMD), so it carries no address arithmetic: DMA sources
+// are a scalar base (advanced with scalar adds) + a fixed 32-bit lane offset, LDS read addresses are
+// fixed registers + the buffer's immediate offset (loop unrolled over the ring).
 // Columns past K / N are fetched from the last legal chunk: they only feed outputs that are discarded.
-__global__ __launch_bounds__(W_NT, 2) void k_wgrad_bf16_dma(const WgradParams p)
+__global__ __launch_bounds__(W_NT) void k_wgrad_bf16_dma(const WgradParams p)
 {
-    constexpr int XB = W_BM * W_TK * 2, GB = W_BM * W_TN * 2, NBUF = 4, OPS = 3;
-    __shared__ __attribute__((aligned(1024))) char lds[NBUF * (XB + GB)];
+    constexpr int XB = W_BM * W_TK * 2, GB = W_BM * W_TN * 2, NBUF = 8, OPS = 3, BUFB = XB + GB;
+    __shared__ __attribute__((aligned(1024))) char lds[NBUF * BUFB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave >> 1, wn = wave & 1;
-    const int kt = blockIdx.x % p.ntk, nt = blockIdx.x / p.ntk;
+    int kt, nt;
+    if (!wgrad_tile(p, kt, nt)) return;
     const int k0 = kt * W_TK, n0 = nt * W_TN;
     const int s_lo = (int)((int64_t)blockIdx.y * p.S / p.nsplit), s_hi = (int)((int64_t)(blockIdx.y + 1) * p.S / p.nsplit);
     const int msteps = p.M / W_BM;
     const int total = (s_hi - s_lo) * msteps;
     const uint32_t edev = rng_epoch_dev(p.rng);
 
-    const char *xsrc[2], *gsrc;
+    // fixed lane offsets (bytes) from the scalar base of a step
+    uint32_t xoff[2], goff;
     {
         const int sc = lane & 15;
 #pragma unroll
@@ -302,23 +349,34 @@ __global__ __launch_bounds__(W_NT, 2) void k_wgrad_bf16_dma(const WgradParams p)
             const int row = 8 * wave + 4 * j + (lane >> 4);
             int col = k0 + 8 * (sc ^ (((row & 3) << 2) | ((row >> 2) & 3)));
             col = col < p.K - 8 ? col : p.K - 8;
-            xsrc[j] = reinterpret_cast<const char *>(p.x) + ((int64_t)row * p.ldx + col) * 2;
+            xoff[j] = (uint32_t)(((int64_t)row * p.ldx + col) * 2);
         }
         const int grow = 8 * wave + (lane >> 3), gsc = lane & 7;
         int gcol = n0 + 8 * (gsc ^ ((((grow & 3) << 2) | ((grow >> 2) & 3)) & 7));
         gcol = gcol < p.N - 8 ? gcol : p.N - 8;
-        gsrc = reinterpret_cast<const char *>(p.gy) + ((int64_t)grow * p.ldgy + gcol) * 2;
+        goff = (uint32_t)(((int64_t)grow * p.ldgy + gcol) * 2);
     }
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-    auto issue = [&](int t) {
-        const int tt = t < total ? t : total - 1;                  // past the end: harmless re-fetch (keeps vmcnt uniform)
-        const int s = s_lo + tt / msteps, m0 = (tt % msteps) * W_BM;
-        const int64_t xo = ((int64_t)s * p.x_sample_stride + (int64_t)m0 * p.ldx) * 2;
-        const int64_t go = ((int64_t)s * p.gy_sample_stride + (int64_t)m0 * p.ldgy) * 2;
-        const uint32_t base = lds0 + (uint32_t)(t % NBUF) * (XB + GB);
-        const char *xs2[2] = {xsrc[0] + xo, xsrc[1] + xo};
-        dma16xN<2>(xs2, 0, base + (uint32_t)wave * 2048u);
-        dma16(reinterpret_cast<const float *>(gsrc + go), base + XB + (uint32_t)wave * 1024u);
+    // issue cursor: running scalar bases of the next 32-row image; a barrier covers TWO images (64 rows)
+    const char *xb = reinterpret_cast<const char *>(p.x) + (int64_t)s_lo * p.x_sample_stride * 2;
+    const char *gb = reinterpret_cast<const char *>(p.gy) + (int64_t)s_lo * p.gy_sample_stride * 2;
+    const int64_t x_img = (int64_t)W_BM * p.ldx * 2, g_img = (int64_t)W_BM * p.ldgy * 2;   // bytes per 32 rows
+    // correction when the cursor passes the last image of a sample: to the next sample's first row
+    const int64_t x_wrap = (p.x_sample_stride - (int64_t)p.M * p.ldx) * 2, g_wrap = (p.gy_sample_stride - (int64_t)p.M * p.ldgy) * 2;
+    int im = 0, left = total;                                      // images issued in this sample / images left to issue
+    auto issue_pair = [&](int pair) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t base = lds0 + (uint32_t)(2 * pair + h) * BUFB;
+            dma16_s3(xb, xoff[0], base + (uint32_t)wave * 2048u, xb, xoff[1], base + (uint32_t)wave * 2048u + 1024u,
+                     gb, goff, base + XB + (uint32_t)wave * 1024u);
+            if (left > 1) {                                        // past the end: harmless re-fetch of the last image
+                --left;
+                xb += x_img;
+                gb += g_img;
+                if (++im == msteps) { im = 0; xb += x_wrap; gb += g_wrap; }
+            }
+        }
     };
 
     WgradAcc A;
@@ -328,28 +386,33 @@ __global__ __launch_bounds__(W_NT, 2) void k_wgrad_bf16_dma(const WgradParams p)
         for (int b = 0; b < 2; ++b) A.acc[a][b] = A.gmu[a][b] = A.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int Q = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    int aoff[4][2], boff[2][2];                                    // tr-read byte offsets, fixed over the loop
+    // tr-read addresses in buffer 0 and in buffer 4 (the ds_read immediate offset reaches 64 KB; the ring is 96 KB)
+    const char *aptr[2][4][2], *bptr[2][2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int c0 = (wk * 64 + a * 16) / 8 + (pp >> 1);
-        aoff[a][0] = img_off<256>(8 * Q + q, c0) + 8 * (pp & 1);
-        aoff[a][1] = img_off<256>(8 * Q + 4 + q, c0) + 8 * (pp & 1);
-    }
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int c0 = (wn * 32 + b * 16) / 8 + (pp >> 1);
-        boff[b][0] = XB + img_off<128>(8 * Q + q, c0) + 8 * (pp & 1);
-        boff[b][1] = XB + img_off<128>(8 * Q + 4 + q, c0) + 8 * (pp & 1);
+        for (int a = 0; a < 4; ++a) {
+            const int c0 = (wk * 64 + a * 16) / 8 + (pp >> 1);
+            aptr[h][a][0] = lds + h * 4 * BUFB + img_off<256>(8 * Q + q, c0) + 8 * (pp & 1);
+            aptr[h][a][1] = lds + h * 4 * BUFB + img_off<256>(8 * Q + 4 + q, c0) + 8 * (pp & 1);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c0 = (wn * 32 + b * 16) / 8 + (pp >> 1);
+            bptr[h][b][0] = lds + h * 4 * BUFB + XB + img_off<128>(8 * Q + q, c0) + 8 * (pp & 1);
+            bptr[h][b][1] = lds + h * 4 * BUFB + XB + img_off<128>(8 * Q + 4 + q, c0) + 8 * (pp & 1);
+        }
     }
-    auto compute = [&](int buf) {
-        const char *X = lds + buf * (XB + GB);
+    auto compute = [&](auto BUF) {
+        constexpr int h = decltype(BUF)::value / 4;
+        constexpr int o = (decltype(BUF)::value % 4) * BUFB;       // immediate offset of the ds_read
         s16x8 af[4], bfr[2];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-            af[a] = __builtin_shufflevector(lds_tr_read(X + aoff[a][0]), lds_tr_read(X + aoff[a][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+            af[a] = __builtin_shufflevector(lds_tr_read(aptr[h][a][0] + o), lds_tr_read(aptr[h][a][1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-            bfr[b] = __builtin_shufflevector(lds_tr_read(X + boff[b][0]), lds_tr_read(X + boff[b][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+            bfr[b] = __builtin_shufflevector(lds_tr_read(bptr[h][b][0] + o), lds_tr_read(bptr[h][b][1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -360,15 +423,26 @@ __global__ __launch_bounds__(W_NT, 2) void k_wgrad_bf16_dma(const WgradParams p)
 
     const int nb = n0 + wn * 32, kb = k0 + wk * 64;
     if (total > 0) {
+        constexpr int NPAIR = NBUF / 2;
 #pragma unroll
-        for (int t = 0; t < NBUF - 1; ++t) issue(t);
-        for (int t = 0; t < total; ++t) {
-            // this wave's pieces of step t have landed (steps t+1, t+2 may still be in flight) ...
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NBUF - 2) * OPS) : "memory");
-            __syncthreads();                                       // ... and everyone else's; buffer (t-1) % NBUF is free
-            issue(t + NBUF - 1);
-            compute(t % NBUF);
-            if ((t + 1) % msteps == 0) wgrad_sample_end(A, p, edev, s_lo + t / msteps, nb, kb);
+        for (int t = 0; t < NPAIR - 1; ++t) issue_pair(t);
+        auto step = [&](auto PAIR) {
+            constexpr int pr = decltype(PAIR)::value;
+            // this wave's pieces of the pair have landed (the next two pairs may still be in flight) ...
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NPAIR - 2) * 2 * OPS) : "memory");
+            __syncthreads();                                       // ... and everyone else's; the previous pair's buffers are free
+            issue_pair((pr + NPAIR - 1) % NPAIR);
+            compute(std::integral_constant<int, 2 * pr>{});
+            compute(std::integral_constant<int, 2 * pr + 1>{});
+        };
+        for (int s = s_lo; s < s_hi; ++s) {                        // msteps % NBUF == 0: every sample starts in buffer 0
+            for (int mi = 0; mi < msteps; mi += NBUF) {
+                step(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 2>{});
+                step(std::integral_constant<int, 3>{});
+            }
+            wgrad_sample_end<true>(A, p, edev, s, nb, kb);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may still be writing this LDS at exit
     }
@@ -383,7 +457,8 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_f32(const WgradParams p)
     __shared__ __attribute__((aligned(16))) float lds[2 * (XF + GF)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave >> 1, wn = wave & 1;
-    const int kt = blockIdx.x % p.ntk, nt = blockIdx.x / p.ntk;
+    int kt, nt;
+    if (!wgrad_tile(p, kt, nt)) return;
     const int k0 = kt * W_TK, n0 = nt * W_TN;
     const int s_lo = (int)((int64_t)blockIdx.y * p.S / p.nsplit), s_hi = (int)((int64_t)(blockIdx.y + 1) * p.S / p.nsplit);
     const int msteps = (p.M + W_BM - 1) / W_BM;
@@ -664,7 +739,8 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
     p.vecX = al16(x) && (xh ? (ldx % 8 == 0 && x_sample_stride % 8 == 0) : (ldx % 4 == 0 && x_sample_stride % 4 == 0));
     p.vecG = al16(gy) && (gh ? (ldgy % 8 == 0 && gy_sample_stride % 8 == 0) : (ldgy % 4 == 0 && gy_sample_stride % 4 == 0));
     p.ntk = (int32_t)((K + W_TK - 1) / W_TK);
-    const int64_t ntn = (N + W_TN - 1) / W_TN, tiles = p.ntk * ntn;
+    p.ntn = (int32_t)((N + W_TN - 1) / W_TN);
+    const int64_t tiles = (int64_t)p.ntk * p.ntn;
     // few tiles (small N * K): split the MC samples over gridDim.y, partials through the workspace
     p.nsplit = 1;
     GemmParams ws{};
@@ -687,8 +763,11 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
         p.g_mu = ws.ws_slabs;
         p.g_rho = nullptr;
     }
-    const dim3 grid((unsigned)tiles, (unsigned)p.nsplit);
-    const bool dma_ok = p.vecX && p.vecG && M % W_BM == 0 && K % 8 == 0 && N % 8 == 0;
+    // diagnostic only (timing split of the loop vs the eps epilogue; results are then NOT the gradient)
+    static const bool diag_noeps = [] { const char *e = getenv("BNN_WGRAD_NOEPS"); return e && e[0] == '1'; }();
+    if (diag_noeps && p.nsplit == 1) p.plain = 1;
+    const dim3 grid((unsigned)(8 * ((p.ntk + 1) / 2) * ((p.ntn + 3) / 4)), (unsigned)p.nsplit);
+    const bool dma_ok = p.vecX && p.vecG && M % (8 * W_BM) == 0 && K % 8 == 0 && N % 8 == 0;
     if (compute == BNN_COMPUTE_F32) {
         hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(W_NT), 0, st, p);
     } else if (xh && gh && dma_ok) {
@@ -740,7 +819,8 @@ int bnn_linear_backward_weight(const void *x, int64_t x_sample_stride, int64_t l
     p.vecX = al16(x) && (xh ? (ldx % 8 == 0 && x_sample_stride % 8 == 0) : (ldx % 4 == 0 && x_sample_stride % 4 == 0));
     p.vecG = al16(gy) && (gh ? (ldgy % 8 == 0 && gy_sample_stride % 8 == 0) : (ldgy % 4 == 0 && gy_sample_stride % 4 == 0));
     p.ntk = (int32_t)((K + W_TK - 1) / W_TK);
-    const dim3 grid((unsigned)(p.ntk * ((N + W_TN - 1) / W_TN)), (unsigned)nsamples);
+    p.ntn = (int32_t)((N + W_TN - 1) / W_TN);
+    const dim3 grid((unsigned)(8 * ((p.ntk + 1) / 2) * ((p.ntn + 3) / 4)), (unsigned)nsamples);
     if (compute == BNN_COMPUTE_F32) hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(W_NT), 0, st, p);
     else if (xh && gh) hipLaunchKernelGGL((k_wgrad_bf16<true, true>), grid, dim3(W_NT), 0, st, p);
     else if (xh) hipLaunchKernelGGL((k_wgrad_bf16<true, false>), grid, dim3(W_NT), 0, st, p);
