@@ -7,6 +7,13 @@ The KL term is eps-independent: every rank reduces a 1/G slice of every posterio
 ONE all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests) carries the packed buffer
     [ KL partial sum per tensor (T)  ||  sum over local samples of the predictions (numel) ].
 At the BASELINE shape that is 6 + 5120 floats = 20.5 KB: latency-bound, one call.
+
+Training adds the gradient exchange: GradAllReducer keeps the gradients of all
+posterior parameters in a few flat fp32 buckets (the .grad tensors are views into them, so the HIP
+backward kernels' results are accumulated straight into the bucket), and all-reduces a bucket as
+soon as the backward pass has produced its last gradient -- the exchange of the later layers runs
+under the backward of the earlier ones.  xGMI is point-to-point (a ring is bound by one ~153 GB/s
+link), so buckets are large and few: 8 MiB by default = 2 buckets for the 19.2 MB of the MLP.
 """
 import torch
 import torch.distributed as dist
@@ -87,3 +94,80 @@ def forward_sharded(net, x, samples, kl_tensors, n_batches=1.0, group=None):
     packed = allreduce_packed(pack(sums, pred_sum), group)
     kl, pred = unpack(packed, numels, samples, pred_sum.shape, n_batches)
     return kl, pred, ys
+
+
+class GradAllReducer:
+    """Bucketed all-reduce of parameter gradients, overlapped with the backward pass.
+
+        red = GradAllReducer(model.parameters())
+        loss.backward()            # buckets are launched from post-accumulate hooks
+        red.finish()               # waits; p.grad now holds the mean over ranks
+        optimizer.step()
+
+    Buckets are filled in REVERSE parameter order (the order backward produces gradients in)."""
+
+    def __init__(self, params, bucket_bytes=8 << 20, group=None, average=True):
+        self.group = group
+        self.average = average
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        params = [p for p in params if p.requires_grad]
+        self.buckets = []          # [flat, [params], pending, handle]
+        cur, size = [], 0
+        for p in reversed(params):
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_bytes:
+                self._close(cur)
+                cur, size = [], 0
+        if cur:
+            self._close(cur)
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for p in b[1]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def _close(self, plist):
+        dev = plist[0].device
+        n = sum(((p.numel() + 3) // 4) * 4 for p in plist)          # 16-B aligned views
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in plist:
+            if p.dtype != torch.float32:
+                raise TypeError("GradAllReducer expects fp32 parameters")
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += ((p.numel() + 3) // 4) * 4
+        self.buckets.append([flat, plist, len(plist), None])
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            b = self.buckets[bi]
+            b[2] -= 1
+            if b[2] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self.world > 1:
+            if self.average:
+                b[0].mul_(1.0 / self.world)
+            b[3] = dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def zero_grad(self):
+        """Zero the buckets in place (keeps the views; use instead of optimizer.zero_grad(set_to_none=True))."""
+        for b in self.buckets:
+            b[0].zero_()
+
+    def finish(self):
+        """Wait for every bucket; launches the ones whose parameters got no gradient this step."""
+        for b in self.buckets:
+            if b[2] != 0 and b[3] is None:
+                self._launch(b)
+            if b[3] is not None:
+                b[3].wait()
+                b[3] = None
+            b[2] = len(b[1])
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

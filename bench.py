@@ -10,7 +10,10 @@ predictive mean over the samples, and -- for N > 1 -- ONE all-reduce over RCCL o
 
 Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel, measured live with
 events on the launch stream), `cpu_baseline` (torch-CPU port of the reference, N = 1 only),
-`f32` (same step in the exact-fp32 parity mode).
+`f32` (same step in the exact-fp32 parity mode), `train` (N = 1: the reference's training-loop
+body, examples/MNIST/train.py:53-65, on the same model -- forward, KL, cross-entropy, HIP
+backward, Adam).  `--mode train` makes the training step the headline value
+(N > 1: MC samples sharded as in the forward, gradients all-reduced in overlapped buckets).
 """
 import argparse
 import json
@@ -83,10 +86,11 @@ def build_net(dev, post):
 class Step:
     """One forward of S samples + KL + predictive mean, optionally captured in a HIP graph.
 
-    Launches per step: 3 fused sampled-GEMM kernels (ReLU folded into the first two), the
-    multi-tensor KL pair on a side stream (it is eps-independent, so it overlaps the GEMMs),
-    the MC reduction, and the epoch bump.  KL sums and the sum of predictions land directly in
-    the packed buffer that the one collective all-reduces."""
+    Launches per step: the multi-tensor KL pair, 3 fused sampled-GEMM kernels (ReLU folded into the
+    first two), and the MC reduction, which also bumps the device epoch -- all on one stream
+    (measured: forking the 13 us of KL onto a second queue costs more in cross-queue dependency
+    latency than it hides).  KL sums and the sum of predictions land directly in the packed buffer
+    that the one collective all-reduces."""
 
     def __init__(self, net, x, rank, world, use_graph):
         from bayesianneuralnetworks_amd import ops, _lib, distributed as bd
@@ -182,6 +186,68 @@ class Step:
         if self.world > 1:
             torch.distributed.all_reduce(self.packed)      # RCCL over xGMI, ~20 KB, latency-bound
         return self.packed
+
+
+class TrainStep:
+    """The reference's training-loop body (examples/MNIST/train.py:53-65): zero_grad, S-sample forward,
+    KL, mean cross-entropy over the samples, backward, Adam.  Forward, KL, and the whole backward of the
+    Bayesian layers (re-drawn weights, fused draw-backward) are HIP; softmax-cross-entropy on the
+    (S*B, 10) logits and Adam are torch.  N > 1: rank r runs MC samples [r*S, (r+1)*S) of the same
+    batch and the gradients are averaged by bucketed all-reduces launched from backward hooks."""
+
+    def __init__(self, net, x, rank, world, use_graph):
+        from bayesianneuralnetworks_amd import _lib, distributed as bd
+        from bayesianneuralnetworks_amd.nn import KLDivergence
+        from bayesianneuralnetworks_amd._rng import default_generator
+        self.net, self.x, self.rank, self.world = net, x, rank, world
+        dev = x.device
+        self.target = torch.randint(0, DIMS[-1], (BATCH,), generator=torch.Generator().manual_seed(3)).to(dev).repeat(SAMPLES)
+        self.kld = KLDivergence(number_of_batches=100)
+        self.graph = None
+        use_graph = use_graph and world == 1
+        self.red = bd.GradAllReducer(net.parameters()) if world > 1 else None
+        self.opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=use_graph, foreach=True)
+        self.loss = torch.zeros((), device=dev)
+        if use_graph:
+            lib = _lib.load()
+            cell = default_generator.epoch_dev(dev)
+            s = torch.cuda.Stream(dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    self._eager()
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                self._body()
+                self.opt.step()
+                # fresh noise on every replay, bumped AFTER the backward re-created this step's draws
+                _lib.check(lib.bnn_rng_advance(_lib.ptr(cell), 1, _lib.stream_ptr(dev)), "bnn_rng_advance")
+            self.graph = g
+
+    def _body(self):
+        ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)      # (S, B, 10)
+        loss = torch.nn.functional.cross_entropy(ys.reshape(SAMPLES * BATCH, -1).float(), self.target) + self.kld(self.net)
+        loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def _eager(self):
+        if self.red is not None:
+            self.red.zero_grad()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+        self._body()
+        if self.red is not None:
+            self.red.finish()
+        self.opt.step()
+
+    def run(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._eager()
 
 
 def time_steps(step, steps, warmup, world, dev):
@@ -305,6 +371,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -342,6 +409,16 @@ def main():
         results[mode] = (world * SAMPLES * steps / dt, dt / steps * 1e3, steps)
     bnn.set_compute(args.dtype)
 
+    # training step (own copy of the model: Adam moves the parameters)
+    train = None
+    if args.mode == "train" or world == 1:
+        tnet = build_net(dev, post)
+        tsteps = args.steps if args.mode == "train" else max(10, args.steps // 4)
+        tstep = TrainStep(tnet, x.bfloat16() if args.dtype == "bf16" else x, rank, world, not args.no_graph)
+        dt = time_steps(tstep, tsteps, args.warmup, world, dev)
+        train = (world * SAMPLES * tsteps / dt, dt / tsteps * 1e3, tsteps, float(tstep.loss))
+        del tstep, tnet
+
     if rank == 0:
         val, ms, steps = results[args.dtype]
         line = {
@@ -359,6 +436,14 @@ def main():
                        "hip_graph": not args.no_graph,
                        "collective": "one all-reduce of [6 KL sums, KL scalar, 512x10 prediction sum] fp32" if world > 1 else None},
         }
+        if train is not None:
+            line["train"] = {"value": round(train[0], 1), "unit": "MC-samples/s", "ms_per_step": round(train[1], 4),
+                             "steps": train[2], "loss": round(train[3], 4), "hip_graph": (not args.no_graph) and world == 1,
+                             "note": "training-loop body of examples/MNIST/train.py:53-65 (fwd + KL + CE + HIP bwd + Adam)"}
+            if args.mode == "train":
+                line["forward"] = {"value": line["value"], "ms_per_step": line["ms_per_step"]}
+                line["metric"] = "MC-samples/sec (node), TRAINING step, 784-1200-1200-10 BayesianLinear MLP, batch 512"
+                line["value"], line["ms_per_step"], line["steps"] = line["train"]["value"], line["train"]["ms_per_step"], train[2]
         if "f32" in results and args.dtype != "f32":
             line["f32"] = {"value": round(results["f32"][0], 1), "ms_per_step": round(results["f32"][1], 4),
                            "note": "same step, exact fp32 MFMA (the 1e-5 parity mode)"}

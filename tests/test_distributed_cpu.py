@@ -101,3 +101,62 @@ def test_two_ranks_match_single_process():
         assert local == 2                                   # 4 samples over 2 ranks
         assert abs(kl - ref_kl) <= 1e-5 * (1 + abs(ref_kl))
         assert np.allclose(pred, ref_pred, atol=1e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ gradient exchange (training)
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.Tanh(), torch.nn.Linear(33, 5))
+    red = bd.GradAllReducer(net.parameters(), bucket_bytes=100)        # 3 buckets at this size
+    outs = []
+    for step in range(2):                                               # views must survive a second step
+        red.zero_grad()
+        x = torch.randn(4, 7, generator=torch.Generator().manual_seed(100 * step + rank))
+        net(x).pow(2).sum().backward()
+        red.finish()
+        outs.append([p.grad.clone().numpy() for p in net.parameters()])
+    q.put((rank, len(red.buckets), outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_equals_mean_of_rank_gradients():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == 3
+    # single-process restatement
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 33), torch.nn.Tanh(), torch.nn.Linear(33, 5))
+    for step in range(2):
+        want = None
+        for r in range(world):
+            net.zero_grad()
+            x = torch.randn(4, 7, generator=torch.Generator().manual_seed(100 * step + r))
+            net(x).pow(2).sum().backward()
+            g = [p.grad.clone().numpy() / world for p in net.parameters()]
+            want = g if want is None else [a + b for a, b in zip(want, g)]
+        for r in range(world):
+            for got, w in zip(res[r][2][step], want):
+                assert np.allclose(got, w, rtol=1e-6, atol=1e-7)
+
+
+def test_gradient_reducer_single_process_keeps_bucket_views():
+    net = torch.nn.Linear(3, 2)
+    red = bd.GradAllReducer(net.parameters())
+    net(torch.ones(1, 3)).sum().backward()
+    red.finish()
+    assert net.weight.grad.data_ptr() == red.buckets[0][0].data_ptr() + 4 * 4   # bias (2 -> 4 floats) first
+    assert torch.equal(net.weight.grad, torch.ones(2, 3))
