@@ -426,13 +426,27 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 
     // prologue: draw chunks 0 .. LA-1, then put the queue in the state the top of iteration 0
     // expects: [R(LA), D(0) .. D(S-2)]
-#pragma unroll
-    for (int c0 = 0; c0 < LA; ++c0) {
-        fetch_unit(rawB, c0);
+    if constexpr (LA == 2) {
+        // both chunks' (mu, rho) in flight at once: one memory round trip instead of two
+        fetch_unit(rawA, 0);
+        fetch_unit(rawB, 1);
+        wait_raw(rawA, std::integral_constant<int, LPU>{});
+        draw_unit(rawA, 0);                     // nch >= 1
+        publish(0);
         wait_raw(rawB, std::integral_constant<int, 0>{});
-        if (c0 < nch) {
-            draw_unit(rawB, c0);
-            publish(c0);
+        if (1 < nch) {
+            draw_unit(rawB, 1);
+            publish(1);
+        }
+    } else {
+#pragma unroll
+        for (int c0 = 0; c0 < LA; ++c0) {
+            fetch_unit(rawB, c0);
+            wait_raw(rawB, std::integral_constant<int, 0>{});
+            if (c0 < nch) {
+                draw_unit(rawB, c0);
+                publish(c0);
+            }
         }
     }
     fetch_unit(rawA, LA);
@@ -568,8 +582,10 @@ static void select_pc(GemmParams &p, hipStream_t st)
         if (p.flags & BNN_FLAG_X_BF16) {
             // bf16 activations: 2-KB stages -> a 3-stage ring and 4 chunk buffers fit easily
             if (p.N <= 16) {
+                // head: 128 x 16 tiles, 256-k chunks (5 hand-offs instead of 19 at K = 1200; measured
+                // against 64 x 16 / 64-k chunks: step 0.1203 -> 0.1168 ms)
                 if (splitk_ok(p, 64, 16, 4)) launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP, true, 4>(p, st);
-                else launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP, true>(p, st);
+                else launch_sym<8, 16, 16, 8, 3, 4, BMODE, CP, true>(p, st);
             } else {
                 launch_sym<16, 32, 48, 2, 3, 4, BMODE, CP, true>(p, st);
             }

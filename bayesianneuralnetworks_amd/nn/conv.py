@@ -9,6 +9,7 @@ import torch
 from torch.distributions import Normal
 
 from .. import ops
+from . import _settings
 from ..utils import _single, _pair, _triple
 from .container import BayesianModule
 from .core import WeightNormal
@@ -144,6 +145,14 @@ class FlipOutNormalConvNd(NormalConvNd):
         # conv.py:182-196 (1d), 213-227 (2d), 244-258 (3d)
         if sample:
             self.sample(x.size(0), self._ones)
+        if x.is_cuda and x.dim() == 4 and type(self)._op is torch.nn.functional.conv2d:
+            # device, 2-d: both contractions are the HIP implicit GEMM (the sign tensors are per EXAMPLE,
+            # conv.py:154-161, so they cannot be folded into the weight)
+            comp = _settings.get_compute()
+            geo = (self.stride, self.padding, self.dilation, self.groups)
+            out = ops.conv2d_plain(x, self.weight.mean.unsqueeze(0), None, True, *geo, comp)[0]
+            noise = ops.conv2d_plain(x * self.S.expand_as(x), self.weight.stddev.unsqueeze(0), None, True, *geo, comp)[0]
+            return out + noise * self.R.expand_as(out)
         conv = type(self)._op
         out = conv(x, self.weight.mean, self.bias, self.stride, self.padding, self.dilation, self.groups)
         noise = conv(x * self.S.expand_as(x), self.weight.stddev, self.bias, self.stride, self.padding,

@@ -27,7 +27,8 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, REF)
 import pytorch_bayesian  # noqa: E402
 from pytorch_bayesian.nn import (NormalLinear, NormalConv2d, KLDivergence,  # noqa: E402
-                                 BayesianNetworkModule, WeightNormal)
+                                 BayesianNetworkModule, WeightNormal, FlipoutNormalLinear,
+                                 FlipOutNormalConv2d)
 from torch.distributions import Normal  # noqa: E402
 
 assert pytorch_bayesian.__version__ == "0.0.4"
@@ -275,7 +276,35 @@ def weightnormal_case():
     print("weightnormal kl", kl_elem.mean().item())
 
 
+def flipout_cases():
+    """dense.py:63-83 and conv.py:145-227: random sign tensors R, S captured from the layer after its own
+    forward (torch.rand on the CPU generator), outputs and autograd gradients."""
+    for name, make, xshape in (
+            ("flipout_linear_12x7", lambda: FlipoutNormalLinear(12, 7), (5, 12)),
+            ("flipout_linear_64x48", lambda: FlipoutNormalLinear(64, 48), (33, 64)),
+            ("flipout_conv_3_4_k3_p1", lambda: FlipOutNormalConv2d(3, 4, 3, padding=1), (2, 3, 10, 10)),
+            # (groups > 1 raises inside the reference itself: S is sized C / groups, conv.py:157-161)
+            ("flipout_conv_4_6_k3_s2", lambda: FlipOutNormalConv2d(4, 6, 3, stride=2, padding=1), (3, 4, 9, 9))):
+        gen = torch.Generator().manual_seed(31)
+        layer = make()
+        seeded_params(layer, gen)
+        x = torch.randn(*xshape, generator=gen)
+        torch.manual_seed(2031)
+        xr = x.clone().requires_grad_(True)
+        y = layer(xr)
+        R, S = layer.sampled
+        gy = torch.randn(*y.shape, generator=gen)
+        (y * gy).sum().backward()
+        np.savez(os.path.join(OUT, name + ".npz"), mu_w=npf(layer.weight.mean), rho_w=npf(layer.weight.scale),
+                 x=npf(x), gy=npf(gy), R=npf(R), S=npf(S), y=npf(y), g_mu_w=npf(layer.weight.mean.grad),
+                 g_rho_w=npf(layer.weight.scale.grad), g_x=npf(xr.grad))
+        print(name, "y", tuple(y.shape))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "flipout":
+        flipout_cases()
+        return
     weightnormal_case()
     linear_case("linear_4x3", 3, 4, True, 11, 5)
     linear_case("linear_7x11", 11, 7, True, 12, 6, prior=Normal(0.05, 0.5))
@@ -289,6 +318,7 @@ def main():
     conv_case("conv_128_128_k3_p1", 128, 128, 3, 1, 1, 1, 1, True, 24, 2, 4, store_params=False)
     pretrained_mnist()
     north_star_mlp()
+    flipout_cases()
 
 
 if __name__ == "__main__":

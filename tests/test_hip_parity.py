@@ -582,6 +582,56 @@ def test_training_step_gradients_match_oracle(env):
     assert np.allclose(N(L1.bias.scale.grad), g_rho_b1 + kr, rtol=1e-4, atol=1e-4)
 
 
+# ------------------------------------------------------------------ Flipout
+@pytest.mark.parametrize("name", ["flipout_linear_12x7", "flipout_linear_64x48"])
+def test_flipout_linear_golden_forward_backward(env, name):
+    """dense.py:63-83 on the device = K1 with eps = outer(R, S) + ONE HIP contraction; outputs and the
+    reference's autograd gradients (mean, scale, x)."""
+    from bayesianneuralnetworks_amd.nn import FlipoutNormalLinear
+    g = load_golden(name)
+    dev = env["dev"]
+    o, i = g["mu_w"].shape
+    layer = FlipoutNormalLinear(i, o).to(dev)
+    with torch.no_grad():
+        layer.weight.mean.copy_(T(g["mu_w"], dev))
+        layer.weight.scale.copy_(T(g["rho_w"], dev))
+    layer.R, layer.S = T(g["R"], dev), T(g["S"], dev)
+    x = T(g["x"], dev).requires_grad_(True)
+    n0 = env["lib"].bnn_launch_count()
+    y = layer(x, sample=False)
+    assert env["lib"].bnn_launch_count() >= n0 + 2
+    assert allclose(N(y), g["y"])
+    (y * T(g["gy"], dev)).sum().backward()
+    assert np.allclose(N(layer.weight.mean.grad), g["g_mu_w"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(N(layer.weight.scale.grad), g["g_rho_w"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(N(x.grad), g["g_x"], rtol=1e-4, atol=1e-5)
+    layer(x)                                            # sample=True draws fresh signs
+    assert set(layer.R.unique().tolist()) <= {-1.0, 1.0} and layer.S.shape == (i,)
+
+
+@pytest.mark.parametrize("name,stride", [("flipout_conv_3_4_k3_p1", 1), ("flipout_conv_4_6_k3_s2", 2)])
+def test_flipout_conv2d_golden_forward_backward(env, name, stride):
+    """conv.py:199-227 on the device: both contractions through the HIP implicit GEMM."""
+    from bayesianneuralnetworks_amd.nn import FlipOutNormalConv2d
+    g = load_golden(name)
+    dev = env["dev"]
+    o, c = g["mu_w"].shape[:2]
+    layer = FlipOutNormalConv2d(c, o, 3, stride=stride, padding=1).to(dev)
+    with torch.no_grad():
+        layer.weight.mean.copy_(T(g["mu_w"], dev))
+        layer.weight.scale.copy_(T(g["rho_w"], dev))
+    layer.R, layer.S = T(g["R"], dev), T(g["S"], dev)
+    x = T(g["x"], dev).requires_grad_(True)
+    n0 = env["lib"].bnn_launch_count()
+    y = layer(x, sample=False)
+    assert env["lib"].bnn_launch_count() >= n0 + 2
+    assert allclose(N(y), g["y"])
+    (y * T(g["gy"], dev)).sum().backward()
+    assert np.allclose(N(layer.weight.mean.grad), g["g_mu_w"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(N(layer.weight.scale.grad), g["g_rho_w"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(N(x.grad), g["g_x"], rtol=1e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------ backward kernels (SURVEY 8f-1)
 def _bwd_case(env, S, M, N, K, seed, shared_x=False):
     from bayesianneuralnetworks_amd._rng import DrawKey

@@ -174,3 +174,23 @@ def test_reference_port_is_bit_identical_to_the_reference():
     y = port.normal_linear(torch.from_numpy(gl["x"]), torch.from_numpy(gl["mu_w"]), torch.from_numpy(gl["rho_w"]),
                            torch.from_numpy(gl["mu_b"]), torch.from_numpy(gl["rho_b"]))
     assert np.array_equal(y.numpy(), gl["y"])
+
+
+# ------------------------------------------------------------------ Flipout
+@pytest.mark.parametrize("name", ["flipout_linear_12x7", "flipout_linear_64x48"])
+def test_flipout_linear_is_sampled_affine_with_rank1_signs(name):
+    """dense.py:78-83: x mu^T + ((x * S) sigma^T) * R == x (mu + sigma * outer(R, S))^T -- the identity the
+    device path uses (eps = outer(R, S) into the K1 / K2 oracles)."""
+    g = load_golden(name)
+    w = orc.sample_affine(g["mu_w"], g["rho_w"], np.outer(g["R"], g["S"]).astype(np.float32))
+    assert allclose(orc.linear(g["x"], w), g["y"])
+    assert set(np.unique(g["R"])) <= {-1.0, 1.0} and set(np.unique(g["S"])) <= {-1.0, 1.0}
+
+
+@pytest.mark.parametrize("name,stride,pad", [("flipout_conv_3_4_k3_p1", 1, 1), ("flipout_conv_4_6_k3_s2", 2, 1)])
+def test_flipout_conv_two_contractions(name, stride, pad):
+    """conv.py:213-227: conv(x, mu) + conv(x * S, sigma) * R with per-example signs."""
+    g = load_golden(name)
+    geo = dict(stride=(stride, stride), padding=(pad, pad))
+    y = orc.conv2d(g["x"], g["mu_w"], None, **geo) + orc.conv2d(g["x"] * g["S"], orc.sigma(g["rho_w"]), None, **geo) * g["R"]
+    assert allclose(y, g["y"])
