@@ -41,6 +41,12 @@ class KlTensor(ctypes.Structure):
                 ("prior_sigma", ctypes.c_float)]
 
 
+class AdamTensor(ctypes.Structure):
+    """bnn_adam_tensor_t"""
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("n", ctypes.c_int64)]
+
+
 class Conv2dShape(ctypes.Structure):
     """bnn_conv2d_shape_t"""
     _fields_ = [(n, ctypes.c_int32) for n in
@@ -84,6 +90,9 @@ SIGNATURES = {
                                           _int, _int, _p]),
     "bnn_colsum": (_int, [_p, _i64, _i64, _p, _i64, _i64, _int, _int, _p]),
     "bnn_relu_backward": (_int, [_p, _p, _p, _i64, _int, _p]),
+    "bnn_adam_step": (_int, [ctypes.POINTER(AdamTensor), _int, _f, _f, _f, _f, _f, _p, _p]),
+    "bnn_xent_workspace_bytes": (_i64, [_i64]),
+    "bnn_softmax_xent": (_int, [_p, _p, _i64, _int, _p, _p, _p, _p]),
     "bnn_conv2d_forward_sampled": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64,
                                           ctypes.POINTER(Conv2dShape), _int, _rngp, _rngp, _int, _int, _p]),
     "bnn_conv2d_forward": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape),

@@ -41,7 +41,7 @@ struct WgradParams {
     const float *rho;           // (N, K)
     float *g_mu, *g_rho;        // (N, K), or the workspace slabs when nsplit > 1
     int64_t slab_stride;        // floats between the partials of two sample groups (nsplit > 1)
-    int32_t M, N, K, S, accumulate, ntk, ntn, nsplit;
+    int32_t M, N, K, S, accumulate, ntk, ntn, nsplit, xcd_map;
     int32_t vecX, vecG;         // 16-B loads legal
     int32_t plain;              // 1: no draw -- out[s] = dW_s per sample (gridDim.y = S), F.linear's own gradient
     RngDev rng;
@@ -112,6 +112,11 @@ __device__ __forceinline__ float4 load4_f32(const float *base, int64_t row_off, 
 // all of both.  gridDim.x = 8 * sub_k * sub_n; workgroups that fall outside the tile grid exit at once.
 __device__ __forceinline__ bool wgrad_tile(const WgradParams &p, int &kt, int &nt)
 {
+    if (!p.xcd_map) {                            // small tile grids: plain order, every workgroup has a tile
+        kt = blockIdx.x % p.ntk;
+        nt = blockIdx.x / p.ntk;
+        return true;
+    }
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int sub_k = (p.ntk + 1) / 2, sub_n = (p.ntn + 3) / 4;
     kt = (xcd & 1) * sub_k + idx % sub_k;
@@ -645,6 +650,30 @@ __global__ __launch_bounds__(256) void k_colsum(const void *__restrict__ gy, int
     if (part == 0 && col < N) out[(int64_t)s * N + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Narrow matrices (N <= 16, e.g. the logits' gradient): 16 columns x 64 row slices per block.
+template <bool GBF>
+__global__ __launch_bounds__(1024) void k_colsum_narrow(const void *__restrict__ gy, int64_t gy_sample_stride, int64_t ldgy,
+                                                        float *__restrict__ out, int M, int N)
+{
+    __shared__ float red[64][17];
+    const int col = threadIdx.x & 15, part = threadIdx.x >> 4, s = blockIdx.x;
+    float a = 0.f;
+    if (col < N) {
+        for (int m = part; m < M; m += 64) {
+            const int64_t o = (int64_t)s * gy_sample_stride + (int64_t)m * ldgy + col;
+            if constexpr (GBF) a += __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(gy)[o] << 16);
+            else a += reinterpret_cast<const float *>(gy)[o];
+        }
+    }
+    red[part][col] = a;
+    __syncthreads();
+    if (threadIdx.x < 16 && threadIdx.x < N) {
+        float t = 0.f;
+        for (int q = 0; q < 64; ++q) t += red[q][threadIdx.x];
+        out[(int64_t)s * N + threadIdx.x] = t;
+    }
+}
+
 // Vector form (N % 8 == 0, 16-B aligned rows): a thread owns 8 columns (one 16-B load per row for bf16,
 // two for fp32); block = 16 column groups x 16 row slices, fixed-order LDS reduction over the slices.
 template <bool GBF>
@@ -766,7 +795,8 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
     // diagnostic only (timing split of the loop vs the eps epilogue; results are then NOT the gradient)
     static const bool diag_noeps = [] { const char *e = getenv("BNN_WGRAD_NOEPS"); return e && e[0] == '1'; }();
     if (diag_noeps && p.nsplit == 1) p.plain = 1;
-    const dim3 grid((unsigned)(8 * ((p.ntk + 1) / 2) * ((p.ntn + 3) / 4)), (unsigned)p.nsplit);
+    p.xcd_map = (p.ntk >= 4 && p.ntn >= 8);
+    const dim3 grid(p.xcd_map ? (unsigned)(8 * ((p.ntk + 1) / 2) * ((p.ntn + 3) / 4)) : (unsigned)tiles, (unsigned)p.nsplit);
     const bool dma_ok = p.vecX && p.vecG && M % (8 * W_BM) == 0 && K % 8 == 0 && N % 8 == 0;
     if (compute == BNN_COMPUTE_F32) {
         hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(W_NT), 0, st, p);
@@ -820,7 +850,8 @@ int bnn_linear_backward_weight(const void *x, int64_t x_sample_stride, int64_t l
     p.vecG = al16(gy) && (gh ? (ldgy % 8 == 0 && gy_sample_stride % 8 == 0) : (ldgy % 4 == 0 && gy_sample_stride % 4 == 0));
     p.ntk = (int32_t)((K + W_TK - 1) / W_TK);
     p.ntn = (int32_t)((N + W_TN - 1) / W_TN);
-    const dim3 grid((unsigned)(8 * ((p.ntk + 1) / 2) * ((p.ntn + 3) / 4)), (unsigned)nsamples);
+    p.xcd_map = (p.ntk >= 4 && p.ntn >= 8);
+    const dim3 grid(p.xcd_map ? (unsigned)(8 * ((p.ntk + 1) / 2) * ((p.ntn + 3) / 4)) : (unsigned)(p.ntk * p.ntn), (unsigned)nsamples);
     if (compute == BNN_COMPUTE_F32) hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(W_NT), 0, st, p);
     else if (xh && gh) hipLaunchKernelGGL((k_wgrad_bf16<true, true>), grid, dim3(W_NT), 0, st, p);
     else if (xh) hipLaunchKernelGGL((k_wgrad_bf16<true, false>), grid, dim3(W_NT), 0, st, p);
@@ -876,6 +907,11 @@ int bnn_colsum(const void *gy, int64_t gy_sample_stride, int64_t ldgy, float *ou
         const dim3 g8((unsigned)((N + 127) / 128), (unsigned)nsamples);
         if (gh) hipLaunchKernelGGL((k_colsum_v8<true>), g8, dim3(256), 0, (hipStream_t)stream, gy, gy_sample_stride, ldgy, out, (int)M, (int)N);
         else hipLaunchKernelGGL((k_colsum_v8<false>), g8, dim3(256), 0, (hipStream_t)stream, gy, gy_sample_stride, ldgy, out, (int)M, (int)N);
+        return check_launch(who);
+    }
+    if (N <= 16) {
+        if (gh) hipLaunchKernelGGL((k_colsum_narrow<true>), dim3((unsigned)nsamples), dim3(1024), 0, (hipStream_t)stream, gy, gy_sample_stride, ldgy, out, (int)M, (int)N);
+        else hipLaunchKernelGGL((k_colsum_narrow<false>), dim3((unsigned)nsamples), dim3(1024), 0, (hipStream_t)stream, gy, gy_sample_stride, ldgy, out, (int)M, (int)N);
         return check_launch(who);
     }
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)nsamples);

@@ -551,3 +551,36 @@ def mc_mean(y, out=None, scale=None, advance=None):
                                  ptr(advance) if advance is not None else None, 1, stream_ptr(y.device)),
           "bnn_mc_sum")
     return out
+
+
+# --------------------------------------------------------------------------- training-loop callers
+class _SoftmaxXent(torch.autograd.Function):
+    """CrossEntropyLoss()(logits, target), reduction 'mean' (examples/MNIST/train.py:39,59-61): the loss
+    and d loss / d logits in one HIP pass."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        require_cuda_f32(logits, "logits")
+        if target.dtype != torch.int64 or not target.is_cuda:
+            raise BnnHipError("cross_entropy: target must be a CUDA int64 tensor")
+        R, C = logits.shape
+        if target.numel() != R:
+            raise BnnHipError("cross_entropy: %d targets for %d rows" % (target.numel(), R))
+        lib = _lib.load()
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        g = torch.empty_like(logits) if logits.requires_grad else None
+        ws = torch.empty(lib.bnn_xent_workspace_bytes(R) // 8, dtype=torch.float64, device=logits.device)
+        check(lib.bnn_softmax_xent(ptr(logits), ptr(target), R, C, ptr(loss), ptr(g), ptr(ws),
+                                   stream_ptr(logits.device)), "bnn_softmax_xent")
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, up):
+        (g,) = ctx.saved_tensors
+        return (g * up if g is not None else None), None
+
+
+def cross_entropy(logits, target):
+    """Mean cross-entropy of (rows, classes) fp32 logits against int64 class indices."""
+    return _SoftmaxXent.apply(logits.contiguous(), target.contiguous())

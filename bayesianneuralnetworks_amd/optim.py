@@ -1,0 +1,49 @@
+"""Optimizer step of the reference's training loop on the device (examples/MNIST/train.py:41,65):
+torch.optim.Adam semantics (amsgrad = False, maximize = False, L2 weight_decay), every parameter
+tensor of the model updated by ONE HIP launch (csrc/bnn_train.hip) -- graph-capturable, the step
+counter lives on the device."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AdamTensor, BnnHipError, check, ptr, stream_ptr
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            arr = (AdamTensor * len(ps))()
+            for i, p in enumerate(ps):
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                    raise BnnHipError("optim.Adam: parameters must be contiguous fp32 tensors on one GPU")
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    raise BnnHipError("optim.Adam: gradients must be contiguous fp32")
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                arr[i].p, arr[i].g = p.data_ptr(), g.data_ptr()
+                arr[i].m, arr[i].v, arr[i].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            if "step" not in group:
+                group["step"] = torch.zeros(1, dtype=torch.float32, device=dev)
+            check(lib.bnn_adam_step(arr, len(ps), float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
+                                    float(group["eps"]), float(group["weight_decay"]), ptr(group["step"]), stream_ptr(dev)),
+                  "bnn_adam_step")
+        return loss

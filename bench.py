@@ -190,13 +190,14 @@ class Step:
 
 class TrainStep:
     """The reference's training-loop body (examples/MNIST/train.py:53-65): zero_grad, S-sample forward,
-    KL, mean cross-entropy over the samples, backward, Adam.  Forward, KL, and the whole backward of the
-    Bayesian layers (re-drawn weights, fused draw-backward) are HIP; softmax-cross-entropy on the
-    (S*B, 10) logits and Adam are torch.  N > 1: rank r runs MC samples [r*S, (r+1)*S) of the same
-    batch and the gradients are averaged by bucketed all-reduces launched from backward hooks."""
+    KL, mean cross-entropy over the samples, backward, Adam.  Forward, KL, the whole backward of the
+    Bayesian layers (re-drawn weights, fused draw-backward), the softmax-cross-entropy on the (S*B, 10)
+    logits and the Adam update (one launch for all 12 tensors) are HIP; autograd's bookkeeping is torch.
+    N > 1: rank r runs MC samples [r*S, (r+1)*S) of the same batch and the gradients are averaged by
+    bucketed all-reduces launched from backward hooks."""
 
     def __init__(self, net, x, rank, world, use_graph):
-        from bayesianneuralnetworks_amd import _lib, distributed as bd
+        from bayesianneuralnetworks_amd import _lib, ops, optim, distributed as bd
         from bayesianneuralnetworks_amd.nn import KLDivergence
         from bayesianneuralnetworks_amd._rng import default_generator
         self.net, self.x, self.rank, self.world = net, x, rank, world
@@ -206,7 +207,8 @@ class TrainStep:
         self.graph = None
         use_graph = use_graph and world == 1
         self.red = bd.GradAllReducer(net.parameters()) if world > 1 else None
-        self.opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=use_graph, foreach=True)
+        self.ops = ops
+        self.opt = optim.Adam(net.parameters(), lr=1e-4)
         self.loss = torch.zeros((), device=dev)
         if use_graph:
             lib = _lib.load()
@@ -229,7 +231,7 @@ class TrainStep:
 
     def _body(self):
         ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)      # (S, B, 10)
-        loss = torch.nn.functional.cross_entropy(ys.reshape(SAMPLES * BATCH, -1).float(), self.target) + self.kld(self.net)
+        loss = self.ops.cross_entropy(ys.reshape(SAMPLES * BATCH, -1), self.target) + self.kld(self.net)
         loss.backward()
         self.loss.copy_(loss.detach())
 

@@ -266,6 +266,28 @@ int bnn_diag_sampler(float *out, int blocks, int iters, int stage, void *stream)
 int bnn_diag_astream(const float *x, int S, int M, int K, int rows_per_wg, int ntn, int pattern,
                      int nwaves, float *out, void *stream);
 
+/* ---- training-loop callers (either side of the backward path) ----------------
+ * replaces  torch.optim.Adam(model.parameters(), lr).step()   examples/MNIST/train.py:41,65
+ *   g += wd p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps),   t = *step + 1; then *step += 1.
+ * All tensors of the model in ONE launch (+ the 1-thread counter bump); `step` is a device float so
+ * that a captured graph advances it. */
+typedef struct bnn_adam_tensor {
+    float *p;
+    const float *g;
+    float *m;
+    float *v;
+    int64_t n;
+} bnn_adam_tensor_t;
+int bnn_adam_step(const bnn_adam_tensor_t *tensors, int ntensors, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float *step, void *stream);
+/* replaces  torch.nn.CrossEntropyLoss()(pred, y)   examples/MNIST/train.py:39,59-61  (reduction 'mean'):
+ *   loss[0] = mean_r (logsumexp(x_r) - x_r[y_r]);  g_logits (may be NULL) = (softmax(x_r) - onehot(y_r)) / rows.
+ * logits (rows, classes) fp32 row-major, target int64; workspace: bnn_xent_workspace_bytes(rows). */
+int64_t bnn_xent_workspace_bytes(int64_t rows);
+int bnn_softmax_xent(const float *logits, const int64_t *target, int64_t rows, int classes,
+                     float *loss, float *g_logits, void *workspace, void *stream);
+
 /* ---- MC reduction ----------------------------------------------------------
  * replaces  torch.stack(preds).mean(0)   examples/MNIST/uncertainty.py:50
  *   out[i] (+)= scale * sum_s y[s * y_sample_stride + i],  i < n.
