@@ -93,10 +93,11 @@ SIGNATURES = {
     "bnn_adam_step": (_int, [ctypes.POINTER(AdamTensor), _int, _f, _f, _f, _f, _f, _p, _p]),
     "bnn_xent_workspace_bytes": (_i64, [_i64]),
     "bnn_softmax_xent": (_int, [_p, _p, _i64, _int, _p, _p, _p, _p]),
+    "bnn_conv2d_workspace_bytes": (_i64, [ctypes.POINTER(Conv2dShape), _int, _int]),
     "bnn_conv2d_forward_sampled": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64,
-                                          ctypes.POINTER(Conv2dShape), _int, _rngp, _rngp, _int, _int, _p]),
+                                          ctypes.POINTER(Conv2dShape), _int, _rngp, _rngp, _int, _int, _p, _i64, _p]),
     "bnn_conv2d_forward": (_int, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape),
-                                  _int, _int, _int, _p]),
+                                  _int, _int, _int, _p, _i64, _p]),
     "bnn_diag_sampler": (_int, [_p, _int, _int, _int, _p]),
     "bnn_diag_astream": (_int, [_p, _int, _int, _int, _int, _int, _int, _int, _p, _p]),
     "bnn_mc_sum": (_int, [_p, _i64, _int, _i64, _f, _p, _int, _p, ctypes.c_uint32, _p]),

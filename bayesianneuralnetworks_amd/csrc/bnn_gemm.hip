@@ -437,12 +437,54 @@ static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
     return dispatch<A_DENSE>(p, sampled, compute, (hipStream_t)stream, who);
 }
 
+// ---- explicit im2col panel for the fast conv path ---------------------------------------------
+// out[(s, b, oh, ow)][(c, kh, kw)] = x[s][b][c][oh*sh - ph + kh*dh][ow*sw - pw + kw*dw] (0 outside), the
+// column order of the weight's (O, C, KH, KW) rows, bf16 (bf16 compute) or fp32.  One thread per 8
+// consecutive columns (K % 8 == 0): 16-B / 32-B stores, coalesced along the row.  The panel then feeds
+// the draw-paced linear kernel (LDS-DMA A rings), whose epilogue stores NCHW.
+template <bool BF>
+__global__ __launch_bounds__(256) void k_im2col(const float *__restrict__ x, int64_t x_sample_stride, void *__restrict__ out,
+                                                int B, int C, int H, int W, int OH, int OW, int KH, int KW,
+                                                int sh_, int sw_, int ph, int pw, int dh, int dw, int K, int64_t groups8)
+{
+    const int KQ = K / 8, P = OH * OW, KHW = KH * KW;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < groups8; id += (int64_t)gridDim.x * 256) {
+        const int kg = (int)(id % KQ);
+        const int64_t mrow = id / KQ;
+        const int s = (int)(mrow / ((int64_t)B * P));
+        const int ml = (int)(mrow % ((int64_t)B * P));
+        const int b = ml / P, pix = ml % P;
+        const int oh = pix / OW, ow = pix % OW;
+        int k = kg * 8;
+        int c = k / KHW, rem = k % KHW;
+        int kh = rem / KW, kw = rem % KW;
+        const float *xb = x + (int64_t)s * x_sample_stride + (int64_t)b * C * H * W;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ih = oh * sh_ - ph + kh * dh, iw = ow * sw_ - pw + kw * dw;
+            v[j] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xb[((int64_t)c * H + ih) * W + iw] : 0.f;
+            if (++kw == KW) { kw = 0; if (++kh == KH) { kh = 0; ++c; } }
+        }
+        if constexpr (BF) {
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(out) + mrow * K + k) = o;
+        } else {
+            float *q = reinterpret_cast<float *>(out) + mrow * K + k;
+            *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
 static int conv_common(const float *x, int64_t x_sample_stride, const float *w, int64_t w_sample_stride,
                        const float *b, int64_t b_sample_stride, const float *mu_w, const float *rho_w,
                        const float *mu_b, const float *rho_b, float *y, int64_t y_sample_stride,
                        const bnn_conv2d_shape_t *sh, int nsamples, const bnn_rng_t *rng_w,
-                       const bnn_rng_t *rng_b, bool sampled, int compute, int flags, void *stream,
-                       const char *who)
+                       const bnn_rng_t *rng_b, bool sampled, int compute, int flags, void *workspace,
+                       int64_t workspace_bytes, void *stream, const char *who)
 {
     if (!x || !y || !sh || (sampled ? (!mu_w || !rho_w) : !w)) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (sampled && ((mu_b == nullptr) != (rho_b == nullptr))) { set_error("%s: mu_b / rho_b must both be given or both NULL", who); return BNN_E_NULL; }
@@ -464,6 +506,41 @@ static int conv_common(const float *x, int64_t x_sample_stride, const float *w, 
         if (mu_b) { rc = check_rng(rng_b, nsamples); if (rc) { set_error("%s: bad rng_b", who); return rc; } }
     }
     if (M == 0) return BNN_OK;
+    // Fast path: explicit im2col panel in the caller's workspace + the draw-paced linear kernel with an
+    // NCHW-storing epilogue (groups == 1, K % 8 == 0, 16-B aligned weights).  Otherwise the generic
+    // implicit-GEMM kernel below (any shape, no workspace).
+    {
+        const int64_t need = bnn_conv2d_workspace_bytes(sh, x_sample_stride == 0 ? 1 : nsamples, compute);
+        static const bool force_v1 = [] { const char *e = getenv("BNN_LINEAR_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
+        const bool fast = !force_v1 && need > 0 && workspace && workspace_bytes >= need && al16(workspace) && al4(y) &&
+                          (compute == BNN_COMPUTE_F32 || compute == BNN_COMPUTE_BF16) && (flags & ~BNN_FLAG_RELU) == 0 &&
+                          (sampled ? (al16(mu_w) && al16(rho_w)) : (al16(w) && w_sample_stride % 4 == 0));
+        if (fast) {
+            const bool bf = compute == BNN_COMPUTE_BF16;
+            const int nsx = x_sample_stride == 0 ? 1 : nsamples;
+            const int64_t groups8 = (int64_t)nsx * M * (K / 8);
+            int64_t blocks = (groups8 + 255) / 256;
+            if (blocks > 65536) blocks = 65536;
+            hipStream_t st = (hipStream_t)stream;
+            if (bf) hipLaunchKernelGGL((k_im2col<true>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, workspace, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
+            else hipLaunchKernelGGL((k_im2col<false>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, workspace, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
+            int rc = check_launch(who);
+            if (rc) return rc;
+            GemmParams q{};
+            q.A = reinterpret_cast<const float *>(workspace); q.a_sample_stride = x_sample_stride == 0 ? 0 : M * K; q.lda = K;
+            q.Bw = w; q.b_sample_stride = w_sample_stride; q.mu = mu_w; q.rho = rho_w;
+            q.bias = sampled ? nullptr : b; q.bias_sample_stride = b_sample_stride;
+            q.mu_b = sampled ? mu_b : nullptr; q.rho_b = sampled ? rho_b : nullptr;
+            q.Y = y; q.y_sample_stride = y_sample_stride; q.ldy = sh->O; q.O = sh->O;
+            q.OH = (int32_t)OH; q.OW = (int32_t)OW;
+            q.M = (int32_t)M; q.N = sh->O; q.K = (int32_t)K; q.S = nsamples; q.G = 1;
+            q.flags = flags | kFlagStoreNCHW | (bf ? BNN_FLAG_X_BF16 : 0);
+            q.vecA = 1; q.vecB = 1;
+            if (sampled) { q.rng_w = make_rng(rng_w); q.rng_b = make_rng(mu_b ? rng_b : nullptr); }
+            fill_workspace(q);
+            return dispatch_linear_v2(q, sampled, compute, st, who);
+        }
+    }
     GemmParams p{};
     p.A = x; p.a_sample_stride = x_sample_stride; p.lda = 0;
     p.C = sh->C; p.H = sh->H; p.W = sh->W; p.OH = (int32_t)OH; p.OW = (int32_t)OW; p.KH = sh->KH; p.KW = sh->KW;
@@ -546,25 +623,38 @@ int bnn_linear_forward(const float *x, int64_t x_sample_stride, int64_t ldx, con
                          false, compute, flags, stream, "bnn_linear_forward");
 }
 
+int64_t bnn_conv2d_workspace_bytes(const bnn_conv2d_shape_t *sh, int x_samples, int compute)
+{
+    if (!sh || x_samples < 1 || sh->groups != 1 || sh->B < 1 || sh->C < 1 || sh->KH < 1 || sh->KW < 1 ||
+        sh->stride_h < 1 || sh->stride_w < 1 || sh->dil_h < 1 || sh->dil_w < 1) return 0;
+    const int64_t OH = ((int64_t)sh->H + 2 * sh->pad_h - (int64_t)sh->dil_h * (sh->KH - 1) - 1) / sh->stride_h + 1;
+    const int64_t OW = ((int64_t)sh->W + 2 * sh->pad_w - (int64_t)sh->dil_w * (sh->KW - 1) - 1) / sh->stride_w + 1;
+    const int64_t K = (int64_t)sh->C * sh->KH * sh->KW;
+    if (OH < 1 || OW < 1 || K % 8 != 0 || K < 32 || sh->O < 16) return 0;     // tiny layers: the generic kernel
+    const int64_t M = (int64_t)sh->B * OH * OW;
+    if (M > 0x7FFFFFFF) return 0;
+    return (int64_t)x_samples * M * K * (compute == BNN_COMPUTE_BF16 ? 2 : 4);
+}
+
 int bnn_conv2d_forward_sampled(const float *x, int64_t x_sample_stride, const float *mu_w,
                                const float *rho_w, const float *mu_b, const float *rho_b, float *y,
                                int64_t y_sample_stride, const bnn_conv2d_shape_t *shape, int nsamples,
                                const bnn_rng_t *rng_w, const bnn_rng_t *rng_b, int compute, int flags,
-                               void *stream)
+                               void *workspace, int64_t workspace_bytes, void *stream)
 {
     return conv_common(x, x_sample_stride, nullptr, 0, nullptr, 0, mu_w, rho_w, mu_b, rho_b, y,
-                       y_sample_stride, shape, nsamples, rng_w, rng_b, true, compute, flags, stream,
-                       "bnn_conv2d_forward_sampled");
+                       y_sample_stride, shape, nsamples, rng_w, rng_b, true, compute, flags, workspace,
+                       workspace_bytes, stream, "bnn_conv2d_forward_sampled");
 }
 
 int bnn_conv2d_forward(const float *x, int64_t x_sample_stride, const float *w, int64_t w_sample_stride,
                        const float *b, int64_t b_sample_stride, float *y, int64_t y_sample_stride,
                        const bnn_conv2d_shape_t *shape, int nsamples, int compute, int flags,
-                       void *stream)
+                       void *workspace, int64_t workspace_bytes, void *stream)
 {
     return conv_common(x, x_sample_stride, w, w_sample_stride, b, b_sample_stride, nullptr, nullptr,
                        nullptr, nullptr, y, y_sample_stride, shape, nsamples, nullptr, nullptr, false,
-                       compute, flags, stream, "bnn_conv2d_forward");
+                       compute, flags, workspace, workspace_bytes, stream, "bnn_conv2d_forward");
 }
 
 }  // extern "C"

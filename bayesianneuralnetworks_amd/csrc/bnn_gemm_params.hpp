@@ -8,6 +8,10 @@ enum { A_DENSE = 0, A_IM2COL = 1 };
 // B_SAMPLED_T: the drawn matrix is used TRANSPOSED (input gradient: reduction over the weight's rows)
 enum { B_PLAIN = 0, B_SAMPLED = 1, B_SAMPLED_T = 2 };
 
+// internal epilogue flag (not part of the C-ABI flags): row m = (image, pixel) -> y[image][n][pixel], i.e. the
+// conv output in NCHW; OH * OW pixels per image, O channels
+constexpr int kFlagStoreNCHW = 1 << 16;
+
 struct GemmParams {
     // A operand
     const float *A;

@@ -524,6 +524,22 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
             bias = p.bias[(int64_t)s * p.bias_sample_stride + n];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
+            if (p.flags & kFlagStoreNCHW) {
+                // conv: rows are (image, pixel); 4 consecutive rows of a lane = consecutive pixels
+                const int P = p.OH * p.OW;
+                const int mb = m0 + wave * RW + a * 16 + fq * 4;
+                int img = mb / P, pix = mb % P;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (mb + r < p.M) {
+                        float v = acc[a][b][r] + bias;
+                        if (p.flags & BNN_FLAG_RELU) v = fmaxf(v, 0.f);
+                        Yb[((int64_t)img * p.O + n) * P + pix] = v;
+                    }
+                    if (++pix == P) { pix = 0; ++img; }
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wave * RW + a * 16 + fq * 4 + r;

@@ -333,6 +333,14 @@ def _conv_shape(x_shape, w_shape, stride, padding, dilation, groups):
     return sh, OH, OW
 
 
+def _conv_workspace(sh, x_samples, compute, device):
+    """im2col panel for the fast conv path (None: the generic kernel runs)."""
+    nbytes = _lib.load().bnn_conv2d_workspace_bytes(ctypes.byref(sh), x_samples, compute)
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
 class _SampledConv2d(torch.autograd.Function):
     """y[s] = conv2d(x[s], w_s, b_s, ...) as an implicit GEMM with in-kernel draws
     (NormalConv2d.forward, conv.py:112-119)."""
@@ -354,10 +362,12 @@ class _SampledConv2d(torch.autograd.Function):
         rw = _rng_struct(key_w, x.device)
         rb = _rng_struct(key_b, x.device) if mu_b is not None else None
         per = sh.B * sh.C * sh.H * sh.W
+        _lib.ensure_workspace(x.device)
+        ws, wsb = _conv_workspace(sh, 1 if shared_x else S, compute, x.device)
         check(_lib.load().bnn_conv2d_forward_sampled(
             ptr(x), 0 if shared_x else per, ptr(mu_w), ptr(rho_w), ptr(mu_b), ptr(rho_b), ptr(y),
             sh.B * sh.O * OH * OW, ctypes.byref(sh), S, ctypes.byref(rw),
-            ctypes.byref(rb) if rb is not None else None, compute, 0, stream_ptr(x.device)),
+            ctypes.byref(rb) if rb is not None else None, compute, 0, ptr(ws), wsb, stream_ptr(x.device)),
             "bnn_conv2d_forward_sampled")
         ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None)
         ctx.key_w, ctx.key_b, ctx.shared_x, ctx.conv_args = key_w, key_b, shared_x, conv_args
@@ -418,8 +428,10 @@ class _PlainConv2d(torch.autograd.Function):
         y = torch.empty((S, sh.B, sh.O, OH, OW), dtype=torch.float32, device=x.device)
         per = sh.B * sh.C * sh.H * sh.W
         wper = w[0].numel()
+        _lib.ensure_workspace(x.device)
+        ws, wsb = _conv_workspace(sh, 1 if shared_x else S, compute, x.device)
         check(_lib.load().bnn_conv2d_forward(ptr(x), 0 if shared_x else per, ptr(w), wper, ptr(b), sh.O, ptr(y),
-                                              sh.B * sh.O * OH * OW, ctypes.byref(sh), S, compute, 0,
+                                              sh.B * sh.O * OH * OW, ctypes.byref(sh), S, compute, 0, ptr(ws), wsb,
                                               stream_ptr(x.device)), "bnn_conv2d_forward")
         ctx.save_for_backward(x, w)
         ctx.shared_x, ctx.conv_args, ctx.has_b = shared_x, conv_args, b is not None

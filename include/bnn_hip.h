@@ -240,19 +240,29 @@ typedef struct bnn_conv2d_shape {
     int32_t O, KH, KW;           /* weight (O, C/groups, KH, KW) */
     int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups;
 } bnn_conv2d_shape_t;
+/* Two kernels behind these entry points.  FAST (groups == 1, K % 8 == 0, O >= 16, 16-B aligned
+ * weights, a workspace of bnn_conv2d_workspace_bytes(shape, x_samples, compute) bytes, 16-B aligned):
+ * an explicit im2col panel (bf16 in bf16 compute) written to the workspace, then the draw-paced
+ * linear kernel (LDS-DMA activation rings, weights drawn once per 512 rows) with an NCHW-storing
+ * epilogue.  GENERIC (workspace NULL / too small, or any other shape): one implicit-GEMM kernel with
+ * scalar im2col loaders.  x_samples = 1 when x_sample_stride == 0 (a shared input is expanded once),
+ * else nsamples.  bnn_conv2d_workspace_bytes returns 0 when only the generic kernel applies. */
+int64_t bnn_conv2d_workspace_bytes(const bnn_conv2d_shape_t *shape, int x_samples, int compute);
 int bnn_conv2d_forward_sampled(const float *x, int64_t x_sample_stride,
                                const float *mu_w, const float *rho_w,
                                const float *mu_b, const float *rho_b,
                                float *y, int64_t y_sample_stride,
                                const bnn_conv2d_shape_t *shape, int nsamples,
                                const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
-                               int compute, int flags, void *stream);
+                               int compute, int flags,
+                               void *workspace, int64_t workspace_bytes, void *stream);
 int bnn_conv2d_forward(const float *x, int64_t x_sample_stride,
                        const float *w, int64_t w_sample_stride,
                        const float *b, int64_t b_sample_stride,
                        float *y, int64_t y_sample_stride,
                        const bnn_conv2d_shape_t *shape, int nsamples,
-                       int compute, int flags, void *stream);
+                       int compute, int flags,
+                       void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- diagnostics ------------------------------------------------------------
  * VALU cost of the draw, no memory traffic: `blocks` workgroups of 256 threads each run

@@ -43,7 +43,7 @@ def test_argument_errors_are_reported_without_launching():
     assert lib.bnn_linear_forward(one, 0, 4, one, 0, None, 0, one, 0, 4, 2, 0, 4, 1, 0, 0, None) == -2
     sh = _lib.Conv2dShape(B=1, C=3, H=5, W=5, O=4, KH=3, KW=3, stride_h=1, stride_w=1, pad_h=0, pad_w=0,
                           dil_h=1, dil_w=1, groups=2)
-    assert lib.bnn_conv2d_forward(one, 0, one, 0, None, 0, one, 0, ctypes.byref(sh), 1, 0, 0, None) == -2
+    assert lib.bnn_conv2d_forward(one, 0, one, 0, None, 0, one, 0, ctypes.byref(sh), 1, 0, 0, None, 0, None) == -2
     assert b"divisible by groups" in lib.bnn_last_error()
     assert lib.bnn_launch_count() == n0
 
