@@ -93,6 +93,9 @@ SIGNATURES = {
     "bnn_adam_step": (_int, [ctypes.POINTER(AdamTensor), _int, _f, _f, _f, _f, _f, _p, _p]),
     "bnn_xent_workspace_bytes": (_i64, [_i64]),
     "bnn_softmax_xent": (_int, [_p, _p, _i64, _int, _p, _p, _p, _p]),
+    "bnn_conv2d_im2col": (_int, [_p, _i64, ctypes.POINTER(Conv2dShape), _int, _p, _int, _p]),
+    "bnn_conv2d_col2im": (_int, [_p, ctypes.POINTER(Conv2dShape), _int, _int, _p, _p]),
+    "bnn_nchw_to_rows": (_int, [_p, _i64, _int, _int, _p, _int, _p]),
     "bnn_conv2d_workspace_bytes": (_i64, [ctypes.POINTER(Conv2dShape), _int, _int]),
     "bnn_conv2d_forward_sampled": (_int, [_p, _i64, _p, _p, _p, _p, _p, _i64,
                                           ctypes.POINTER(Conv2dShape), _int, _rngp, _rngp, _int, _int, _p, _i64, _p]),

@@ -479,6 +479,69 @@ __global__ __launch_bounds__(256) void k_im2col(const float *__restrict__ x, int
     }
 }
 
+// Inverse of the panel for the input gradient: gx[s][b][c][ih][iw] = sum over the kernel taps (kh, kw) that
+// reach (ih, iw) of gpanel[(s, b, oh, ow)][(c, kh, kw)] -- a gather (no atomics, one thread per input
+// element, fixed summation order).  SHARED: the input was shared by all samples, so sum over s as well.
+__global__ __launch_bounds__(256) void k_col2im(const float *__restrict__ gp, float *__restrict__ gx, int nsamples, int shared,
+                                                int B, int C, int H, int W, int OH, int OW, int KH, int KW,
+                                                int sh_, int sw_, int ph, int pw, int dh, int dw, int64_t total)
+{
+    const int K = C * KH * KW, P = OH * OW;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int iw = (int)(id % W);
+        int64_t t = id / W;
+        const int ih = (int)(t % H); t /= H;
+        const int c = (int)(t % C); t /= C;
+        const int b = (int)(t % B);
+        const int s0 = (int)(t / B);                       // 0 when shared
+        float acc = 0.f;
+        const int s_lo = shared ? 0 : s0, s_hi = shared ? nsamples : s0 + 1;
+        for (int s = s_lo; s < s_hi; ++s) {
+            const float *base = gp + ((int64_t)s * B + b) * P * K + (int64_t)c * KH * KW;
+            for (int kh = 0; kh < KH; ++kh) {
+                const int th = ih + ph - kh * dh;
+                if (th < 0 || th % sh_ != 0) continue;
+                const int oh = th / sh_;
+                if (oh >= OH) continue;
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int tw = iw + pw - kw * dw;
+                    if (tw < 0 || tw % sw_ != 0) continue;
+                    const int ow = tw / sw_;
+                    if (ow >= OW) continue;
+                    acc += base[(int64_t)(oh * OW + ow) * K + kh * KW + kw];
+                }
+            }
+        }
+        gx[id] = acc;
+    }
+}
+
+// (images, O, P) NCHW -> rows [(image, pixel)][O], fp32 or bf16: the gy operand of the linear backward kernels.
+template <bool BF>
+__global__ __launch_bounds__(256) void k_nchw_to_rows(const float *__restrict__ y, void *__restrict__ out, int O, int P, int64_t total)
+{
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int o = (int)(id % O);
+        const int64_t m = id / O;
+        const int64_t img = m / P;
+        const int pix = (int)(m % P);
+        const float v = y[(img * O + o) * P + pix];
+        if constexpr (BF) reinterpret_cast<uint16_t *>(out)[id] = f2bf(v);
+        else reinterpret_cast<float *>(out)[id] = v;
+    }
+}
+
+static int conv_geometry(const bnn_conv2d_shape_t *sh, int64_t &OH, int64_t &OW, const char *who)
+{
+    if (!sh) { set_error("%s: NULL shape", who); return BNN_E_NULL; }
+    if (sh->B < 1 || sh->C < 1 || sh->H < 1 || sh->W < 1 || sh->KH < 1 || sh->KW < 1 || sh->stride_h < 1 || sh->stride_w < 1 ||
+        sh->pad_h < 0 || sh->pad_w < 0 || sh->dil_h < 1 || sh->dil_w < 1 || sh->groups != 1) { set_error("%s: bad shape (groups must be 1)", who); return BNN_E_SHAPE; }
+    OH = ((int64_t)sh->H + 2 * sh->pad_h - (int64_t)sh->dil_h * (sh->KH - 1) - 1) / sh->stride_h + 1;
+    OW = ((int64_t)sh->W + 2 * sh->pad_w - (int64_t)sh->dil_w * (sh->KW - 1) - 1) / sh->stride_w + 1;
+    if (OH < 1 || OW < 1) { set_error("%s: empty output", who); return BNN_E_SHAPE; }
+    return BNN_OK;
+}
+
 static int conv_common(const float *x, int64_t x_sample_stride, const float *w, int64_t w_sample_stride,
                        const float *b, int64_t b_sample_stride, const float *mu_w, const float *rho_w,
                        const float *mu_b, const float *rho_b, float *y, int64_t y_sample_stride,
@@ -621,6 +684,54 @@ int bnn_linear_forward(const float *x, int64_t x_sample_stride, int64_t ldx, con
     return linear_common(x, x_sample_stride, ldx, w, w_sample_stride, b, b_sample_stride, nullptr, nullptr,
                          nullptr, nullptr, y, y_sample_stride, ldy, M, N, K, nsamples, nullptr, nullptr,
                          false, compute, flags, stream, "bnn_linear_forward");
+}
+
+int bnn_conv2d_im2col(const float *x, int64_t x_sample_stride, const bnn_conv2d_shape_t *sh, int x_samples,
+                      void *panel, int out_bf16, void *stream)
+{
+    const char *who = "bnn_conv2d_im2col";
+    int64_t OH, OW;
+    int rc = conv_geometry(sh, OH, OW, who);
+    if (rc) return rc;
+    if (!x || !panel) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    const int64_t K = (int64_t)sh->C * sh->KH * sh->KW, M = (int64_t)sh->B * OH * OW;
+    if (K % 8 != 0 || x_samples < 1 || M > 0x7FFFFFFF || !al16(panel)) { set_error("%s: needs C*KH*KW %% 8 == 0, a 16-B aligned panel", who); return BNN_E_UNSUPPORTED; }
+    const int64_t groups8 = (int64_t)x_samples * M * (K / 8);
+    int64_t blocks = (groups8 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipStream_t st = (hipStream_t)stream;
+    if (out_bf16) hipLaunchKernelGGL((k_im2col<true>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, panel, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
+    else hipLaunchKernelGGL((k_im2col<false>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, panel, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
+    return check_launch(who);
+}
+
+int bnn_conv2d_col2im(const float *gpanel, const bnn_conv2d_shape_t *sh, int nsamples, int shared_x, float *gx, void *stream)
+{
+    const char *who = "bnn_conv2d_col2im";
+    int64_t OH, OW;
+    int rc = conv_geometry(sh, OH, OW, who);
+    if (rc) return rc;
+    if (!gpanel || !gx || nsamples < 1) { set_error("%s: NULL pointer / nsamples < 1", who); return BNN_E_NULL; }
+    const int64_t total = (int64_t)(shared_x ? 1 : nsamples) * sh->B * sh->C * sh->H * sh->W;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_col2im, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gpanel, gx, nsamples, shared_x ? 1 : 0,
+                       sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w,
+                       sh->dil_h, sh->dil_w, total);
+    return check_launch(who);
+}
+
+int bnn_nchw_to_rows(const float *y, int64_t images, int channels, int pixels, void *rows, int out_bf16, void *stream)
+{
+    const char *who = "bnn_nchw_to_rows";
+    if (!y || !rows) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (images < 1 || channels < 1 || pixels < 1) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    const int64_t total = images * channels * pixels;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (out_bf16) hipLaunchKernelGGL((k_nchw_to_rows<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, rows, channels, pixels, total);
+    else hipLaunchKernelGGL((k_nchw_to_rows<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, rows, channels, pixels, total);
+    return check_launch(who);
 }
 
 int64_t bnn_conv2d_workspace_bytes(const bnn_conv2d_shape_t *sh, int x_samples, int compute)

@@ -370,7 +370,7 @@ class _SampledConv2d(torch.autograd.Function):
             ctypes.byref(rb) if rb is not None else None, compute, 0, ptr(ws), wsb, stream_ptr(x.device)),
             "bnn_conv2d_forward_sampled")
         ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None)
-        ctx.key_w, ctx.key_b, ctx.shared_x, ctx.conv_args = key_w, key_b, shared_x, conv_args
+        ctx.key_w, ctx.key_b, ctx.shared_x, ctx.conv_args, ctx.compute = key_w, key_b, shared_x, conv_args, compute
         return y
 
     @staticmethod
@@ -379,9 +379,14 @@ class _SampledConv2d(torch.autograd.Function):
         stride, padding, dilation, groups = ctx.conv_args
         S = ctx.key_w.nsamples
         gy = gy.contiguous()
-        gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
         need_x = ctx.needs_input_grad[0]
         need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        need_b = rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        sh, OH, OW = _conv_shape(x.shape[-4:], mu_w.shape, stride, padding, dilation, groups)
+        K = mu_w[0].numel()
+        if groups == 1 and K % 8 == 0 and sh.O % 8 == 0:
+            return _SampledConv2d._backward_panel(ctx, gy, sh, OH, OW, need_x, need_w, need_b)
+        gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
         if need_x or need_w:
             w = _sample_affine_philox_raw(mu_w, rho_w, ctx.key_w)          # (S, O, Cg, KH, KW)
             gxs, gws = [], []
@@ -396,8 +401,52 @@ class _SampledConv2d(torch.autograd.Function):
             if need_w:
                 gw = torch.stack(gws)
                 g_mu_w, g_rho_w = _sample_affine_bwd_raw(gw, rho_w, rho_w.numel(), S, key=ctx.key_w)
-        if rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+        if need_b:
             gb = gy.sum((1, 3, 4))
+            g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None
+
+    @staticmethod
+    def _backward_panel(ctx, gy, sh, OH, OW, need_x, need_w, need_b):
+        """All-HIP backward through the im2col panel (include/bnn_hip.h, 'backward of K2 conv2d'): the conv is
+        the linear layer rows = (image, pixel), so the linear backward kernels (re-drawn weights, fused
+        draw-backward) do the work; only the layout changes (NCHW -> rows, col2im) are conv-specific."""
+        x, mu_w, rho_w, rho_b = ctx.saved_tensors
+        S, compute, dev = ctx.key_w.nsamples, ctx.compute, gy.device
+        lib = _lib.load()
+        _lib.ensure_workspace(dev)
+        st = stream_ptr(dev)
+        P, O = OH * OW, sh.O
+        M, K = sh.B * P, mu_w[0].numel()
+        bf = compute == _lib.COMPUTE_BF16
+        adt = torch.bfloat16 if bf else torch.float32
+        rows = torch.empty((S, M, O), dtype=adt, device=dev)
+        check(lib.bnn_nchw_to_rows(ptr(gy), S * sh.B, O, P, ptr(rows), int(bf), st), "bnn_nchw_to_rows")
+        rw = _rng_struct(ctx.key_w, dev)
+        gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
+        aflag = _lib.FLAG_X_BF16 if bf else 0
+        if need_w:
+            nsx = 1 if ctx.shared_x else S
+            panel = torch.empty((nsx, M, K), dtype=adt, device=dev)
+            per = sh.B * sh.C * sh.H * sh.W
+            check(lib.bnn_conv2d_im2col(ptr(x), 0 if ctx.shared_x else per, ctypes.byref(sh), nsx, ptr(panel), int(bf), st),
+                  "bnn_conv2d_im2col")
+            g_mu_w = torch.empty_like(mu_w)
+            g_rho_w = torch.empty_like(rho_w)
+            check(lib.bnn_linear_backward_weight_sampled(ptr(panel), 0 if ctx.shared_x else M * K, K, ptr(rows), M * O, O,
+                                                         ptr(rho_w), ptr(g_mu_w), ptr(g_rho_w), M, O, K, S, ctypes.byref(rw),
+                                                         compute, aflag | (_lib.FLAG_Y_BF16 if bf else 0), 0, st),
+                  "bnn_linear_backward_weight_sampled")
+        if need_x:
+            gpanel = torch.empty((S, M, K), dtype=torch.float32, device=dev)
+            check(lib.bnn_linear_backward_input_sampled(ptr(rows), M * O, O, ptr(mu_w), ptr(rho_w), ptr(gpanel), M * K, K,
+                                                        M, O, K, S, ctypes.byref(rw), compute, aflag, st),
+                  "bnn_linear_backward_input_sampled")
+            gx = torch.empty((sh.B, sh.C, sh.H, sh.W) if ctx.shared_x else (S, sh.B, sh.C, sh.H, sh.W),
+                             dtype=torch.float32, device=dev)
+            check(lib.bnn_conv2d_col2im(ptr(gpanel), ctypes.byref(sh), S, int(ctx.shared_x), ptr(gx), st), "bnn_conv2d_col2im")
+        if need_b:
+            gb = _colsum_raw(rows)                                          # (S, O)
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
         return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None
 

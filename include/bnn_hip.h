@@ -264,6 +264,22 @@ int bnn_conv2d_forward(const float *x, int64_t x_sample_stride,
                        int compute, int flags,
                        void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- backward of K2 conv2d through the panel ------------------
+ * replaces  autograd through F.conv2d (conv.py:116) for groups == 1, C*KH*KW % 8 == 0.  With
+ * M = B*OH*OW rows, K = C*KH*KW, N = O:
+ *   rows  = bnn_nchw_to_rows(gy)                 gy (S*B, O, OH*OW) -> (S*B*OH*OW, O), fp32 or bf16
+ *   panel = bnn_conv2d_im2col(x)                 (x_samples*M, K), fp32 or bf16 (the forward's panel)
+ *   bnn_linear_backward_weight_sampled(panel, rows, ...)   -> g_mu, g_rho of the (O, K) weight
+ *   bnn_linear_backward_input_sampled(rows, ...) -> gpanel (S*M, K) fp32
+ *   bnn_conv2d_col2im(gpanel)                    -> gx (S | 1, B, C, H, W), gather (no atomics);
+ *                                                   shared_x != 0 also sums over the samples. */
+int bnn_conv2d_im2col(const float *x, int64_t x_sample_stride, const bnn_conv2d_shape_t *shape,
+                      int x_samples, void *panel, int out_bf16, void *stream);
+int bnn_conv2d_col2im(const float *gpanel, const bnn_conv2d_shape_t *shape, int nsamples,
+                      int shared_x, float *gx, void *stream);
+int bnn_nchw_to_rows(const float *y, int64_t images, int channels, int pixels, void *rows,
+                     int out_bf16, void *stream);
+
 /* ---- diagnostics ------------------------------------------------------------
  * VALU cost of the draw, no memory traffic: `blocks` workgroups of 256 threads each run
  * `iters` Philox blocks (4 draws) of stage 0 (Philox4x32-10 only), 1 (+ Box-Muller),

@@ -790,6 +790,58 @@ def test_full_size_backward_properties(env):
     assert all(torch.isfinite(t.float()).all() for t in gs)
 
 
+# ------------------------------------------------------------------ conv2d backward through the panel
+@pytest.mark.parametrize("cfg", [
+    # (S, B, C, H, W, O, k, stride, pad, dil, bias, shared_x)
+    (2, 3, 8, 6, 6, 16, 3, 2, 1, 1, True, False),
+    (3, 2, 8, 7, 5, 24, 3, 1, 1, 2, False, True),
+    (2, 4, 64, 6, 6, 64, 3, 2, 1, 1, True, False),       # MNIST / FMNIST conv shape
+])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_sampled_conv2d_backward_vs_float64_autograd(env, cfg, mode):
+    """Sampled conv2d backward, all HIP (NCHW -> rows, im2col panel, fused weight / input gradient kernels,
+    col2im): against float64 autograd through F.conv2d (conv.py:116) on the oracle's draws."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    S, B, C, H, W, O, k, st, pd, dl, bias, shared = cfg
+    orc, dev = env["orc"], env["dev"]
+    gen = torch.Generator().manual_seed(17)
+    mu = torch.randn(O, C, k, k, generator=gen) * 0.1
+    rho = torch.randn(O, C, k, k, generator=gen) * 0.15 - 2.0
+    mub = torch.randn(O, generator=gen) * 0.1
+    rhob = torch.randn(O, generator=gen) * 0.15 - 2.0
+    x = torch.randn((B, C, H, W) if shared else (S, B, C, H, W), generator=gen)
+    kw, kb = DrawKey(5, 40, 0, S, 3), DrawKey(5, 41, 0, S, 3)
+    xd = x.to(dev).requires_grad_(True)
+    md, rd = mu.to(dev).requires_grad_(True), rho.to(dev).requires_grad_(True)
+    mbd, rbd = (mub.to(dev).requires_grad_(True), rhob.to(dev).requires_grad_(True)) if bias else (None, None)
+    n0 = env["lib"].bnn_launch_count()
+    y = env["ops"].conv2d_sampled(xd, md, rd, mbd, rbd, kw, kb if bias else None, shared, (st, st), (pd, pd), (dl, dl), 1, mode)
+    gy = torch.randn(y.shape, generator=gen)
+    grads = torch.autograd.grad(y, [xd, md, rd] + ([mbd, rbd] if bias else []), gy.to(dev))
+    assert env["lib"].bnn_launch_count() >= n0 + 7           # fwd 2 + rows, im2col, wgrad, dgrad, col2im
+    # float64 restatement
+    x64 = x.double().requires_grad_(True)
+    m64, r64 = mu.double().requires_grad_(True), rho.double().requires_grad_(True)
+    mb64, rb64 = mub.double().requires_grad_(True), rhob.double().requires_grad_(True)
+    ys = []
+    for s_ in range(S):
+        ew = torch.from_numpy(orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, tuple(mu.shape))).double()
+        w = m64 + (1e-10 + torch.nn.functional.softplus(r64)) * ew
+        b_ = None
+        if bias:
+            eb = torch.from_numpy(orc.eps_fill(kb.seed, kb.stream, s_, kb.epoch_host, 0, (O,))).double()
+            b_ = mb64 + (1e-10 + torch.nn.functional.softplus(rb64)) * eb
+        ys.append(torch.nn.functional.conv2d(x64 if shared else x64[s_], w, b_, st, pd, dl))
+    y64 = torch.stack(ys)
+    tol_y = 1e-5 if mode == "f32" else 2e-2
+    assert allclose_scaled(N(y), y64.detach().numpy(), tol_y)
+    want = torch.autograd.grad(y64, [x64, m64, r64] + ([mb64, rb64] if bias else []), gy.double())
+    tol = 2e-5 if mode == "f32" else 3e-2
+    for got, w_ in zip(grads, want):
+        assert got.shape == w_.shape
+        assert allclose_scaled(N(got), w_.numpy(), tol)
+
+
 # ------------------------------------------------------------------ training-loop callers
 def test_fused_adam_matches_torch_adam(env):
     """optim.Adam (one HIP launch for all tensors) against torch.optim.Adam (train.py:41,65) over 6 steps,
