@@ -5,7 +5,7 @@
 One step = one stochastic forward of S = 8 MC samples over one synthetic batch of 512
 (all samples of a layer in one fused sampled-GEMM launch), the Gaussian KL once, the
 predictive mean over the samples, and -- for N > 1 -- ONE all-reduce over RCCL of the packed
-[KL sums || sum of predictions] buffer.  Weak scaling: every rank runs its own 8 samples
+[KL sums || sum of predictions] buffer, issued asynchronously so that it runs under the next step.  Weak scaling: every rank runs its own 8 samples
 (sample ids rank*8 .. rank*8+7 of the same posterior), value = N * 8 * steps / time.
 
 Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel, measured live with
@@ -120,6 +120,8 @@ class Step:
         self.kl_tmp = torch.zeros(self.Tl + 1, device=dev)
         self.kl_pos = torch.tensor(self.kl_idx, device=dev, dtype=torch.long)
         self.side = torch.cuda.Stream(dev)
+        self.comm = torch.zeros_like(self.packed)
+        self.pending = None
         if use_graph:
             self._capture()
 
@@ -184,8 +186,21 @@ class Step:
         else:
             self._body()
         if self.world > 1:
-            torch.distributed.all_reduce(self.packed)      # RCCL over xGMI, ~20 KB, latency-bound
+            # RCCL over xGMI, ~20 KB, latency-bound -- so it runs UNDER the next step: the step's result is
+            # copied to a communication buffer (stream-ordered, 20 KB) and all-reduced asynchronously; the
+            # next replay overwrites `packed`, not the buffer, and the buffer is not reused before its
+            # previous reduction has finished (stream-level wait, no host block).
+            if self.pending is not None:
+                self.pending.wait()
+            self.comm.copy_(self.packed)
+            self.pending = torch.distributed.all_reduce(self.comm, async_op=True)
+            return self.comm
         return self.packed
+
+    def finish(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
 
 
 class TrainStep:
@@ -261,6 +276,8 @@ def time_steps(step, steps, warmup, world, dev):
     t0 = time.perf_counter()
     for _ in range(steps):
         step.run()
+    if hasattr(step, "finish"):
+        step.finish()                                   # the last step's collective is inside the timed region
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
