@@ -84,8 +84,8 @@ SIGNATURES = {
     "bnn_linear_backward_input_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int,
                                                  _rngp, _int, _int, _p]),
     "bnn_linear_backward_input": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p]),
-    "bnn_linear_backward_weight_sampled": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64,
-                                                  _int, _rngp, _int, _int, _int, _p]),
+    "bnn_linear_backward_weight_sampled": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64,
+                                                  _i64, _int, _rngp, _rngp, _int, _int, _int, _p]),
     "bnn_linear_backward_weight": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _int,
                                           _int, _int, _p]),
     "bnn_colsum": (_int, [_p, _i64, _i64, _p, _i64, _i64, _int, _int, _p]),

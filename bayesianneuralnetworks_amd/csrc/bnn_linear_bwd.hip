@@ -45,6 +45,11 @@ struct WgradParams {
     int32_t vecX, vecG;         // 16-B loads legal
     int32_t plain;              // 1: no draw -- out[s] = dW_s per sample (gridDim.y = S), F.linear's own gradient
     RngDev rng;
+    // optional fused bias gradient (nsplit == 1 only): the workgroups of k-tile 0 also take the column sums
+    // of gy (one extra MFMA against a fragment of ones per n-subtile and step) and apply the bias draw's backward
+    const float *rho_b;
+    float *g_mu_b, *g_rho_b;
+    RngDev rng_b;
 };
 
 constexpr int W_TK = 128, W_TN = 64, W_BM = 32, W_NT = 256;
@@ -129,6 +134,43 @@ __device__ __forceinline__ bool wgrad_tile(const WgradParams &p, int &kt, int &n
 struct WgradAcc {
     f32x4 acc[4][2], gmu[4][2], grho[4][2];
 };
+
+// Fused bias gradient.  Each of the 4 waves of a k-tile-0 workgroup takes ONE 16-column subtile (wave (wk, wn):
+// columns nb + 16 wk ..), so the extra MFMA per step is spread evenly.  cs = running column sums of gy over the
+// current sample (every row of the MFMA result is the same sum; row 0 = lanes 0..15, element 0, is used).
+struct WgradBias {
+    f32x4 cs;
+    float gmu, grho;
+};
+
+__device__ __forceinline__ void wgrad_bias_init(WgradBias &Bz)
+{
+    Bz.cs = f32x4{0.f, 0.f, 0.f, 0.f};
+    Bz.gmu = Bz.grho = 0.f;
+}
+
+__device__ __forceinline__ void wgrad_bias_sample_end(WgradBias &Bz, const WgradParams &p, uint32_t edev_b, int s, int nbias)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = nbias + lane;
+    const float cs = Bz.cs[0];
+    if (lane < 16 && n < p.N) {
+        Bz.gmu += cs;
+        Bz.grho = fmaf(cs, eps1(p.rng_b, edev_b, (uint64_t)n, p.rng_b.sample0 + (uint32_t)s), Bz.grho);
+    }
+    Bz.cs = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+__device__ __forceinline__ void wgrad_bias_store(const WgradBias &Bz, const WgradParams &p, int nbias)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = nbias + lane;
+    if (lane >= 16 || n >= p.N) return;
+    float gm = Bz.gmu, gr = Bz.grho * dsoftplus(p.rho_b[n]);
+    if (p.accumulate) { gm += p.g_mu_b[n]; gr += p.g_rho_b[n]; }
+    p.g_mu_b[n] = gm;
+    p.g_rho_b[n] = gr;
+}
 
 // UNCOND: draw eps for every accumulator tile, in range or not (out-of-range outputs are discarded by
 // wgrad_store) -- one straight-line block, so the independent Philox chains of the 8 tiles interleave.
@@ -276,6 +318,11 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_bf16(const WgradParams p)
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) A.acc[a][b] = A.gmu[a][b] = A.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool bias_wave = p.g_mu_b != nullptr && kt == 0;         // fused bias gradient: subtile wk of this wave's two
+    const uint32_t edev_b = bias_wave ? rng_epoch_dev(p.rng_b) : 0u;
+    WgradBias Bz;
+    wgrad_bias_init(Bz);
+    const s16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
 
     // transposed-read addressing: lane = 16 Q + 4 q + pp supplies row (8Q [+4] + q), columns 4 pp .. 4 pp + 3
     // of a 16-column block and receives column (lane & 15), rows 8Q [+4] .. +3
@@ -303,6 +350,9 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_bf16(const WgradParams p)
             for (int b = 0; b < 2; ++b)
                 A.acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
                                                                       __builtin_bit_cast(bf16x8, bfr[b]), A.acc[a][b], 0, 0, 0);
+        if (bias_wave)
+            Bz.cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones8),
+                                                            __builtin_bit_cast(bf16x8, wk ? bfr[1] : bfr[0]), Bz.cs, 0, 0, 0);
     };
 
     const int nb = n0 + wn * 32, kb = k0 + wk * 64;
@@ -316,9 +366,13 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_bf16(const WgradParams p)
         compute(t & 1);
         if (t + 1 < total) stage((t + 1) & 1);
         __syncthreads();
-        if ((t + 1) % msteps == 0) wgrad_sample_end(A, p, edev, s_lo + t / msteps, nb, kb);
+        if ((t + 1) % msteps == 0) {
+            wgrad_sample_end(A, p, edev, s_lo + t / msteps, nb, kb);
+            if (bias_wave) wgrad_bias_sample_end(Bz, p, edev_b, s_lo + t / msteps, nb + 16 * wk);
+        }
     }
     wgrad_store(A, p, nb, kb);
+    if (bias_wave) wgrad_bias_store(Bz, p, nb + 16 * wk);
 }
 
 // Same contraction for the hot case -- x and gy both bf16 in memory, M % 256 == 0, K % 8 == 0, N % 8 == 0:
@@ -390,6 +444,12 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_bf16_dma(const WgradParams p)
 #pragma unroll
         for (int b = 0; b < 2; ++b) A.acc[a][b] = A.gmu[a][b] = A.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool bias_wave = p.g_mu_b != nullptr && kt == 0;         // fused bias gradient: subtile wk of this wave's two
+    const uint32_t edev_b = bias_wave ? rng_epoch_dev(p.rng_b) : 0u;
+    WgradBias Bz;
+    wgrad_bias_init(Bz);
+    const s16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
+
     const int Q = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     // tr-read addresses in buffer 0 and in buffer 4 (the ds_read immediate offset reaches 64 KB; the ring is 96 KB)
     const char *aptr[2][4][2], *bptr[2][2][2];
@@ -424,6 +484,9 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_bf16_dma(const WgradParams p)
             for (int b = 0; b < 2; ++b)
                 A.acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
                                                                       __builtin_bit_cast(bf16x8, bfr[b]), A.acc[a][b], 0, 0, 0);
+        if (bias_wave)
+            Bz.cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones8),
+                                                            __builtin_bit_cast(bf16x8, wk ? bfr[1] : bfr[0]), Bz.cs, 0, 0, 0);
     };
 
     const int nb = n0 + wn * 32, kb = k0 + wk * 64;
@@ -448,10 +511,12 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_bf16_dma(const WgradParams p)
                 step(std::integral_constant<int, 3>{});
             }
             wgrad_sample_end<true>(A, p, edev, s, nb, kb);
+            if (bias_wave) wgrad_bias_sample_end(Bz, p, edev_b, s, nb + 16 * wk);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may still be writing this LDS at exit
     }
     wgrad_store(A, p, nb, kb);
+    if (bias_wave) wgrad_bias_store(Bz, p, nb + 16 * wk);
 }
 
 // ------------------------------------------------------------------ exact fp32
@@ -503,6 +568,11 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_f32(const WgradParams p)
 #pragma unroll
         for (int b = 0; b < 2; ++b) A.acc[a][b] = A.gmu[a][b] = A.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool bias_wave = p.g_mu_b != nullptr && kt == 0;         // fused bias gradient: subtile wk of this wave's two
+    const uint32_t edev_b = bias_wave ? rng_epoch_dev(p.rng_b) : 0u;
+    WgradBias Bz;
+    wgrad_bias_init(Bz);
+
     const int Q = lane >> 4, g = lane & 15;
     auto compute = [&](int buf) {
         const float *X = lds + buf * (XF + GF), *G = X + XF;
@@ -518,6 +588,7 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_f32(const WgradParams p)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     A.acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], A.acc[a][b], 0, 0, 0);
+            if (bias_wave) Bz.cs = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, wk ? bv[1] : bv[0], Bz.cs, 0, 0, 0);
         }
     };
 
@@ -532,9 +603,13 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_f32(const WgradParams p)
         compute(t & 1);
         if (t + 1 < total) stage((t + 1) & 1);
         __syncthreads();
-        if ((t + 1) % msteps == 0) wgrad_sample_end(A, p, edev, s_lo + t / msteps, nb, kb);
+        if ((t + 1) % msteps == 0) {
+            wgrad_sample_end(A, p, edev, s_lo + t / msteps, nb, kb);
+            if (bias_wave) wgrad_bias_sample_end(Bz, p, edev_b, s_lo + t / msteps, nb + 16 * wk);
+        }
     }
     wgrad_store(A, p, nb, kb);
+    if (bias_wave) wgrad_bias_store(Bz, p, nb + 16 * wk);
 }
 
 // Fixed-order sum of the sample-group partials (nsplit > 1), then sigmoid(rho) on the rho part.
@@ -744,12 +819,15 @@ extern "C" {
 
 int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
                                        const void *gy, int64_t gy_sample_stride, int64_t ldgy,
-                                       const float *rho_w, float *g_mu, float *g_rho, int64_t M, int64_t N,
-                                       int64_t K, int nsamples, const bnn_rng_t *rng_w, int compute,
-                                       int flags, int accumulate, void *stream)
+                                       const float *rho_w, float *g_mu, float *g_rho, const float *rho_b,
+                                       float *g_mu_b, float *g_rho_b, int64_t M, int64_t N,
+                                       int64_t K, int nsamples, const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
+                                       int compute, int flags, int accumulate, void *stream)
 {
     const char *who = "bnn_linear_backward_weight_sampled";
     if (!x || !gy || !rho_w || !g_mu || !g_rho) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    const bool want_bias = rho_b || g_mu_b || g_rho_b;
+    if (want_bias && (!rho_b || !g_mu_b || !g_rho_b || !rng_b)) { set_error("%s: rho_b, g_mu_b, g_rho_b, rng_b must be given together", who); return BNN_E_NULL; }
     if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldgy < N) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
     if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || N * K > ((int64_t)1 << 34)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
     if (K % 4 == 0 && (!al16(g_mu) || !al16(g_rho))) { set_error("%s: gradients must be 16-B aligned", who); return BNN_E_ALIGN; }
@@ -758,6 +836,7 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
     if (compute != BNN_COMPUTE_F32 && compute != BNN_COMPUTE_BF16) { set_error("%s: unknown compute mode %d", who, compute); return BNN_E_DTYPE; }
     int rc = check_rng(rng_w, nsamples);
     if (rc) { set_error("%s: bad rng_w", who); return rc; }
+    if (want_bias) { rc = check_rng(rng_b, nsamples); if (rc) { set_error("%s: bad rng_b", who); return rc; } }
     hipStream_t st = (hipStream_t)stream;
     WgradParams p{};
     p.x = x; p.x_sample_stride = x_sample_stride; p.ldx = ldx;
@@ -778,19 +857,31 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
         if (!accumulate) {
             rc = (int)hipMemsetAsync(g_mu, 0, (size_t)(N * K) * 4, st);
             if (!rc) rc = (int)hipMemsetAsync(g_rho, 0, (size_t)(N * K) * 4, st);
+            if (!rc && want_bias) rc = (int)hipMemsetAsync(g_mu_b, 0, (size_t)N * 4, st);
+            if (!rc && want_bias) rc = (int)hipMemsetAsync(g_rho_b, 0, (size_t)N * 4, st);
             if (rc) { set_error("%s: hipMemsetAsync failed (%d)", who, rc); return rc; }
         }
         return BNN_OK;
     }
     if (tiles < 64 && nsamples > 1 && ws.ws_slabs) {
         int ns = nsamples < 8 ? nsamples : 8;
-        while (ns > 1 && (int64_t)ns * 2 * N * K * 4 > ws.ws_slab_bytes) --ns;
+        while (ns > 1 && ((int64_t)ns * 2 * N * K + (int64_t)nsamples * N) * 4 > ws.ws_slab_bytes) --ns;
         p.nsplit = ns;
     }
     if (p.nsplit > 1) {
         p.slab_stride = 2 * N * K;
         p.g_mu = ws.ws_slabs;
         p.g_rho = nullptr;
+        if (want_bias) {
+            // the sample split leaves no workgroup that sees every sample: column sums and the bias draw's
+            // backward as two small launches (scratch: S x N floats behind the partial slabs)
+            float *tmp = ws.ws_slabs + (int64_t)p.nsplit * p.slab_stride;
+            rc = bnn_colsum(gy, gy_sample_stride, ldgy, tmp, M, N, nsamples, gh ? BNN_FLAG_X_BF16 : 0, stream);
+            if (!rc) rc = bnn_sample_affine_bwd(tmp, N, rho_b, nullptr, 0, rng_b, N, nsamples, g_mu_b, g_rho_b, accumulate, stream);
+            if (rc) return rc;
+        }
+    } else if (want_bias) {
+        p.rho_b = rho_b; p.g_mu_b = g_mu_b; p.g_rho_b = g_rho_b; p.rng_b = make_rng(rng_b);
     }
     // diagnostic only (timing split of the loop vs the eps epilogue; results are then NOT the gradient)
     static const bool diag_noeps = [] { const char *e = getenv("BNN_WGRAD_NOEPS"); return e && e[0] == '1'; }();

@@ -250,15 +250,24 @@ class _SampledLinear(torch.autograd.Function):
                 gx = _dgrad_plain_raw(gy, w, gx_dtype)
             if ctx.shared_x:
                 gx = _sum_samples(gx).to(x.dtype)
+        need_b = rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             g_mu_w = torch.empty_like(mu_w)
             g_rho_w = torch.empty_like(rho_w)
             flags = (_lib.FLAG_X_BF16 if _bf(x) else 0) | (_lib.FLAG_Y_BF16 if _bf(gy) else 0)
+            rb = None
+            if need_b:                                                     # bias gradient rides in the same launch
+                g_mu_b = torch.empty_like(rho_b)
+                g_rho_b = torch.empty_like(rho_b)
+                rb = _rng_struct(ctx.key_b, dev)
             check(lib.bnn_linear_backward_weight_sampled(ptr(x), 0 if ctx.shared_x else M * K, K, ptr(gy), M * N, N,
-                                                         ptr(rho_w), ptr(g_mu_w), ptr(g_rho_w), M, N, K, S,
-                                                         ctypes.byref(rw), compute, flags, 0, stream_ptr(dev)),
+                                                         ptr(rho_w), ptr(g_mu_w), ptr(g_rho_w),
+                                                         ptr(rho_b) if need_b else None, ptr(g_mu_b), ptr(g_rho_b),
+                                                         M, N, K, S, ctypes.byref(rw),
+                                                         ctypes.byref(rb) if rb is not None else None,
+                                                         compute, flags, 0, stream_ptr(dev)),
                   "bnn_linear_backward_weight_sampled")
-        if rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+        elif need_b:
             gb = _colsum_raw(gy)                                           # (S, N)
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
         return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None
@@ -433,10 +442,19 @@ class _SampledConv2d(torch.autograd.Function):
                   "bnn_conv2d_im2col")
             g_mu_w = torch.empty_like(mu_w)
             g_rho_w = torch.empty_like(rho_w)
+            rb = None
+            if need_b:
+                g_mu_b = torch.empty_like(rho_b)
+                g_rho_b = torch.empty_like(rho_b)
+                rb = _rng_struct(ctx.key_b, dev)
             check(lib.bnn_linear_backward_weight_sampled(ptr(panel), 0 if ctx.shared_x else M * K, K, ptr(rows), M * O, O,
-                                                         ptr(rho_w), ptr(g_mu_w), ptr(g_rho_w), M, O, K, S, ctypes.byref(rw),
+                                                         ptr(rho_w), ptr(g_mu_w), ptr(g_rho_w),
+                                                         ptr(rho_b) if need_b else None, ptr(g_mu_b), ptr(g_rho_b),
+                                                         M, O, K, S, ctypes.byref(rw),
+                                                         ctypes.byref(rb) if rb is not None else None,
                                                          compute, aflag | (_lib.FLAG_Y_BF16 if bf else 0), 0, st),
                   "bnn_linear_backward_weight_sampled")
+            need_b = False
         if need_x:
             gpanel = torch.empty((S, M, K), dtype=torch.float32, device=dev)
             check(lib.bnn_linear_backward_input_sampled(ptr(rows), M * O, O, ptr(mu_w), ptr(rho_w), ptr(gpanel), M * K, K,

@@ -209,13 +209,18 @@ int bnn_linear_backward_input(const void *gy, int64_t gy_sample_stride, int64_t 
  * x: (S, M, K) or shared (x_sample_stride = 0).  flags: BNN_FLAG_X_BF16 = x is bf16,
  * BNN_FLAG_Y_BF16 = gy is bf16 (bf16 compute only).  With few output tiles
  * the MC samples are split over workgroups through the registered workspace and added in a fixed
- * order: bitwise reproducible. */
+ * order: bitwise reproducible.
+ * Bias (rho_b, g_mu_b, g_rho_b, rng_b all given, or all NULL): g_mu_b[n] (+)= sum_s c_s[n],
+ * g_rho_b[n] (+)= sum_s c_s[n] * eps_b,s[n] * sigmoid(rho_b[n]), c_s = column sums of gy[s] -- taken
+ * inside the same launch by the workgroups of k-tile 0 (one extra MFMA against a fragment of ones per
+ * step), or by bnn_colsum + bnn_sample_affine_bwd when the samples are split. */
 int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
                                        const void *gy, int64_t gy_sample_stride, int64_t ldgy,
                                        const float *rho_w, float *g_mu, float *g_rho,
+                                       const float *rho_b, float *g_mu_b, float *g_rho_b,
                                        int64_t M, int64_t N, int64_t K, int nsamples,
-                                       const bnn_rng_t *rng_w, int compute, int flags,
-                                       int accumulate, void *stream);
+                                       const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
+                                       int compute, int flags, int accumulate, void *stream);
 /* F.linear's own weight gradient, per sample: gw[s][n][k] (+)= sum_m gy[s][m][n] * x[s][m][k],
  * gw[s] = gw + s * gw_sample_stride (parity mode, where the draw is a separate op). */
 int bnn_linear_backward_weight(const void *x, int64_t x_sample_stride, int64_t ldx,

@@ -723,6 +723,54 @@ def test_backward_kernels_bf16_mode(env, S, M, Nn, K):
         assert allclose_scaled(N(g_mu), exact_mu, 2e-2) and allclose_scaled(N(gx.float()), exact_x, 2e-2)
 
 
+@pytest.mark.parametrize("mode,M", [("f32", 70), ("bf16", 256), ("bf16", 72)])
+def test_bias_gradient_fused_into_weight_gradient(env, mode, M):
+    """>= 64 output tiles: the k-tile-0 workgroups of the weight-gradient launch also produce the bias
+    gradient (column sums by an MFMA against ones, bias draw's backward in the epilogue).  bf16 with
+    M % 256 == 0 takes the LDS-DMA kernel, M = 72 the register-staged one."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    orc, dev = env["orc"], env["dev"]
+    S, Nn, K = 2, 520, 1024
+    gen = torch.Generator().manual_seed(21)
+    mu = torch.randn(Nn, K, generator=gen) * 0.05
+    rho = torch.randn(Nn, K, generator=gen) * 0.15 - 2.0
+    mub = torch.randn(Nn, generator=gen) * 0.05
+    rhob = torch.randn(Nn, generator=gen) * 0.15 - 2.0
+    x = torch.randn(S, M, K, generator=gen)
+    gy = torch.randn(S, M, Nn, generator=gen)
+    kw, kb = DrawKey(77, 5, 0, S, 2), DrawKey(77, 6, 0, S, 2)
+    adt = torch.float32 if mode == "f32" else torch.bfloat16
+    xd = x.to(dev).to(adt)
+    mbd, rbd = mub.to(dev).requires_grad_(True), rhob.to(dev).requires_grad_(True)
+    n0 = env["lib"].bnn_launch_count()
+    y = env["ops"].linear_sampled(xd, mu.to(dev), rho.to(dev), mbd, rbd, kw, kb, False, compute=mode, out_dtype=adt)
+    # bias gradient alone: needs neither the weight-gradient launch nor the fused path
+    g_mu_b0, g_rho_b0 = torch.autograd.grad(y, (mbd, rbd), gy.to(dev).to(adt), retain_graph=True)
+    md, rd = mu.to(dev).requires_grad_(True), rho.to(dev).requires_grad_(True)
+    y = env["ops"].linear_sampled(xd, md, rd, mbd, rbd, kw, kb, False, compute=mode, out_dtype=adt)
+    n1 = env["lib"].bnn_launch_count()
+    g_mu_w, g_rho_w, g_mu_b, g_rho_b = torch.autograd.grad(y, (md, rd, mbd, rbd), gy.to(dev).to(adt))
+    assert env["lib"].bnn_launch_count() == n1 + 1            # ONE launch: weights and bias together
+    rnd = (lambda a: a) if mode == "f32" else orc.bf16_round
+    want_mu = np.zeros(Nn)
+    want_rho = np.zeros(Nn)
+    for s_ in range(S):
+        cs = rnd(N(gy[s_])).astype(np.float64).sum(0)
+        eb = orc.eps_fill(kb.seed, kb.stream, s_, kb.epoch_host, 0, (Nn,))
+        a, b = orc.sample_affine_bwd(np.ones(Nn, np.float32), N(rhob), eb)
+        want_mu += cs * a
+        want_rho += cs * b
+    tol = 1e-5 if mode == "f32" else 2e-3
+    for got in (g_mu_b, g_mu_b0):
+        assert allclose_scaled(N(got), want_mu, tol)
+    for got in (g_rho_b, g_rho_b0):
+        assert allclose_scaled(N(got), want_rho, tol)
+    ew = [orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, (Nn, K)) for s_ in range(S)]
+    wm, wr, _ = _oracle_linear_bwd(orc, mu, rho, x, gy, ew, False, rounder=rnd)
+    assert allclose_scaled(N(g_mu_w), wm, tol) and allclose_scaled(N(g_rho_w), wr, tol)
+    del n0
+
+
 def test_bias_colsum_and_relu_mask_kernels(env):
     dev = env["dev"]
     gy = torch.randn(3, 37, 130, device=dev)
@@ -757,8 +805,8 @@ def test_weight_gradient_is_bitwise_reproducible_and_accumulates(env):
             gm = torch.full((Nn, K), 1.0, device=dev)
             gr = torch.full((Nn, K), 2.0, device=dev)
             _lib.check(env["lib"].bnn_linear_backward_weight_sampled(
-                _lib.ptr(xd), M * K, K, _lib.ptr(gyd), M * Nn, Nn, _lib.ptr(rhod), _lib.ptr(gm), _lib.ptr(gr),
-                M, Nn, K, S, ctypes.byref(r), _lib.COMPUTE_F32, 0, acc, _lib.stream_ptr(dev)), "wgrad")
+                _lib.ptr(xd), M * K, K, _lib.ptr(gyd), M * Nn, Nn, _lib.ptr(rhod), _lib.ptr(gm), _lib.ptr(gr), None, None, None,
+                M, Nn, K, S, ctypes.byref(r), None, _lib.COMPUTE_F32, 0, acc, _lib.stream_ptr(dev)), "wgrad")
             outs.append((gm, gr))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert torch.allclose(outs[2][0], outs[0][0] + 1.0, rtol=1e-6, atol=1e-6)
