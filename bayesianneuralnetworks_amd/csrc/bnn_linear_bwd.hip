@@ -519,6 +519,196 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_bf16_dma(const WgradParams p)
     if (bias_wave) wgrad_bias_store(Bz, p, nb + 16 * wk);
 }
 
+// Two-role version of the kernel above (512 threads): waves 0..3 run the MFMA loop and nothing else; waves
+// 4..7 -- one per SIMD beside an MFMA wave -- issue ALL the LDS-DMA (with its scalar bookkeeping and the
+// vmcnt waits) and draw the eps of the CURRENT sample, one Philox block between two barriers, into a
+// 32-KB LDS image that the MFMA waves read once at the end of the sample.  Measured: 54.5 -> 48.6 us at the
+// layer-2 shape -- the MFMA loop itself drops to 29 us (no issue overhead), but a VALU-heavy wave and an
+// MFMA-heavy wave on one SIMD add up rather than overlap, so the 19 us of eps draws are not hidden (spreading
+// them evenly over all pair steps, 8 interleaved chains, measured WORSE: 65 us).  Both roles execute the same barriers: one per pair of
+// images and one (E) per sample, after the helper's last eps write; the helper's first write of the next
+// sample comes after the next pair barrier, which the MFMA waves pass only after their eps reads.
+__global__ __launch_bounds__(2 * W_NT) void k_wgrad_bf16_dma8(const WgradParams p)
+{
+    constexpr int XB = W_BM * W_TK * 2, GB = W_BM * W_TN * 2, NBUF = 8, OPS = 3, BUFB = XB + GB, NPAIR = NBUF / 2;
+    constexpr int EPSB = 4 * 8 * 64 * 16;                          // [wave][tile][lane] float4
+    __shared__ __attribute__((aligned(1024))) char lds[NBUF * BUFB + EPSB];
+    char *eps_lds = lds + NBUF * BUFB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = wave8 >= 4;
+    const int wave = wave8 & 3;                                    // the MFMA wave this wave is, or serves
+    const int wk = wave >> 1, wn = wave & 1;
+    int kt, nt;
+    if (!wgrad_tile(p, kt, nt)) return;
+    const int k0 = kt * W_TK, n0 = nt * W_TN;
+    const int s_lo = (int)((int64_t)blockIdx.y * p.S / p.nsplit), s_hi = (int)((int64_t)(blockIdx.y + 1) * p.S / p.nsplit);
+    const int msteps = p.M / W_BM;                                 // images per sample, a multiple of NBUF
+    const int total = (s_hi - s_lo) * msteps;
+    const int nb = n0 + wn * 32, kb = k0 + wk * 64;
+    if (total <= 0) {                                              // (cannot happen: nsplit <= S)
+        if (!helper) { WgradAcc Z; for (int a = 0; a < 4; ++a) for (int b = 0; b < 2; ++b) Z.acc[a][b] = Z.gmu[a][b] = Z.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; wgrad_store(Z, p, nb, kb); }
+        return;
+    }
+
+    if (helper) {
+        // ---------------------------------------------------------------- DMA + eps role
+        const uint32_t edev = rng_epoch_dev(p.rng);
+        uint32_t xoff[2], goff;
+        {
+            const int sc = lane & 15;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 8 * wave + 4 * j + (lane >> 4);
+                int col = k0 + 8 * (sc ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+                col = col < p.K - 8 ? col : p.K - 8;
+                xoff[j] = (uint32_t)(((int64_t)row * p.ldx + col) * 2);
+            }
+            const int grow = 8 * wave + (lane >> 3), gsc = lane & 7;
+            int gcol = n0 + 8 * (gsc ^ ((((grow & 3) << 2) | ((grow >> 2) & 3)) & 7));
+            gcol = gcol < p.N - 8 ? gcol : p.N - 8;
+            goff = (uint32_t)(((int64_t)grow * p.ldgy + gcol) * 2);
+        }
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+        const char *xb = reinterpret_cast<const char *>(p.x) + (int64_t)s_lo * p.x_sample_stride * 2;
+        const char *gb = reinterpret_cast<const char *>(p.gy) + (int64_t)s_lo * p.gy_sample_stride * 2;
+        const int64_t x_img = (int64_t)W_BM * p.ldx * 2, g_img = (int64_t)W_BM * p.ldgy * 2;
+        const int64_t x_wrap = (p.x_sample_stride - (int64_t)p.M * p.ldx) * 2, g_wrap = (p.gy_sample_stride - (int64_t)p.M * p.ldgy) * 2;
+        int im = 0, left = total;
+        auto issue_pair = [&](int pair) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t base = lds0 + (uint32_t)(2 * pair + h) * BUFB;
+                dma16_s3(xb, xoff[0], base + (uint32_t)wave * 2048u, xb, xoff[1], base + (uint32_t)wave * 2048u + 1024u,
+                         gb, goff, base + XB + (uint32_t)wave * 1024u);
+                if (left > 1) {                                    // past the end: harmless re-fetch of the last image
+                    --left;
+                    xb += x_img;
+                    gb += g_img;
+                    if (++im == msteps) { im = 0; xb += x_wrap; gb += g_wrap; }
+                }
+            }
+        };
+        const int pairs = msteps / 2;                              // pair barriers per sample (a multiple of 4)
+        const int gen_every = pairs / 4;                           // 4 draw points per sample, TWO Philox blocks each: two
+                                                                   // independent chains interleave (a lone chain is latency-bound)
+        float4 *my_eps = reinterpret_cast<float4 *>(eps_lds) + (wave * 8) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NPAIR - 1; ++t) issue_pair(t);
+        for (int s = s_lo; s < s_hi; ++s) {
+            const uint32_t sample = p.rng.sample0 + (uint32_t)s;
+            int tile = 0;
+            for (int pr = 0; pr < pairs; ++pr) {
+                // this wave's pieces of the pair have landed (the next two pairs may still be in flight) ...
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NPAIR - 2) * 2 * OPS) : "memory");
+                __syncthreads();                                   // ... and everyone else's; the previous pair's buffers are free
+                issue_pair((pr + NPAIR - 1) % NPAIR);
+                if (!p.plain && pr % gen_every == 0) {
+                    // tiles (a, 0) and (a, 1): same k, n and n + 16
+                    const int a = tile >> 1;
+                    const int n = nb + (lane & 15), k = kb + a * 16 + 4 * (lane >> 4);
+                    const float4 z0 = eps4(p.rng, edev, (uint32_t)(((int64_t)n * p.K + k) >> 2), sample);
+                    const float4 z1 = eps4(p.rng, edev, (uint32_t)(((int64_t)(n + 16) * p.K + k) >> 2), sample);
+                    my_eps[tile * 64] = z0;
+                    my_eps[(tile + 1) * 64] = z1;
+                    tile += 2;
+                }
+            }
+            __syncthreads();                                       // E: this sample's eps image is complete
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing may still be writing this LDS at exit
+        return;
+    }
+
+    // -------------------------------------------------------------------- MFMA role
+    WgradAcc A;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) A.acc[a][b] = A.gmu[a][b] = A.grho[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool bias_wave = p.g_mu_b != nullptr && kt == 0;         // fused bias gradient: subtile wk of this wave's two
+    const uint32_t edev_b = bias_wave ? rng_epoch_dev(p.rng_b) : 0u;
+    WgradBias Bz;
+    wgrad_bias_init(Bz);
+    const s16x8 ones8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
+
+    const int Q = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const char *aptr[2][4][2], *bptr[2][2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int c0 = (wk * 64 + a * 16) / 8 + (pp >> 1);
+            aptr[h][a][0] = lds + h * 4 * BUFB + img_off<256>(8 * Q + q, c0) + 8 * (pp & 1);
+            aptr[h][a][1] = lds + h * 4 * BUFB + img_off<256>(8 * Q + 4 + q, c0) + 8 * (pp & 1);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c0 = (wn * 32 + b * 16) / 8 + (pp >> 1);
+            bptr[h][b][0] = lds + h * 4 * BUFB + XB + img_off<128>(8 * Q + q, c0) + 8 * (pp & 1);
+            bptr[h][b][1] = lds + h * 4 * BUFB + XB + img_off<128>(8 * Q + 4 + q, c0) + 8 * (pp & 1);
+        }
+    }
+    auto compute = [&](auto BUF) {
+        constexpr int h = decltype(BUF)::value / 4;
+        constexpr int o = (decltype(BUF)::value % 4) * BUFB;       // immediate offset of the ds_read
+        s16x8 af[4], bfr[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            af[a] = __builtin_shufflevector(lds_tr_read(aptr[h][a][0] + o), lds_tr_read(aptr[h][a][1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            bfr[b] = __builtin_shufflevector(lds_tr_read(bptr[h][b][0] + o), lds_tr_read(bptr[h][b][1] + o), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                A.acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
+                                                                      __builtin_bit_cast(bf16x8, bfr[b]), A.acc[a][b], 0, 0, 0);
+        if (bias_wave)
+            Bz.cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones8),
+                                                            __builtin_bit_cast(bf16x8, wk ? bfr[1] : bfr[0]), Bz.cs, 0, 0, 0);
+    };
+    auto step = [&](auto PAIR) {
+        constexpr int pr = decltype(PAIR)::value;
+        __syncthreads();                                           // the pair's images have landed (helper waves waited for them)
+        compute(std::integral_constant<int, 2 * pr>{});
+        compute(std::integral_constant<int, 2 * pr + 1>{});
+    };
+    const float4 *my_eps = reinterpret_cast<const float4 *>(eps_lds) + (wave * 8) * 64 + lane;
+    for (int s = s_lo; s < s_hi; ++s) {                            // msteps % NBUF == 0: every sample starts in buffer 0
+        for (int mi = 0; mi < msteps; mi += NBUF) {
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+        }
+        __syncthreads();                                           // E: the eps image of this sample is complete
+        if (!p.plain) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float4 z = my_eps[(a * 2 + b) * 64];
+                    A.grho[a][b][0] = fmaf(A.acc[a][b][0], z.x, A.grho[a][b][0]);
+                    A.grho[a][b][1] = fmaf(A.acc[a][b][1], z.y, A.grho[a][b][1]);
+                    A.grho[a][b][2] = fmaf(A.acc[a][b][2], z.z, A.grho[a][b][2]);
+                    A.grho[a][b][3] = fmaf(A.acc[a][b][3], z.w, A.grho[a][b][3]);
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                A.gmu[a][b] += A.acc[a][b];
+                A.acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        if (bias_wave) wgrad_bias_sample_end(Bz, p, edev_b, s, nb + 16 * wk);
+    }
+    wgrad_store(A, p, nb, kb);
+    if (bias_wave) wgrad_bias_store(Bz, p, nb + 16 * wk);
+}
+
 // ------------------------------------------------------------------ exact fp32
 __global__ __launch_bounds__(W_NT) void k_wgrad_f32(const WgradParams p)
 {
@@ -892,7 +1082,10 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
     if (compute == BNN_COMPUTE_F32) {
         hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(W_NT), 0, st, p);
     } else if (xh && gh && dma_ok) {
-        hipLaunchKernelGGL(k_wgrad_bf16_dma, grid, dim3(W_NT), 0, st, p);
+        // two-role kernel (MFMA waves + DMA / eps waves) unless BNN_WGRAD_ROLES=1 asks for the one-role one
+        static const bool one_role = [] { const char *e = getenv("BNN_WGRAD_ROLES"); return e && e[0] == '1'; }();
+        if (one_role) hipLaunchKernelGGL(k_wgrad_bf16_dma, grid, dim3(W_NT), 0, st, p);
+        else hipLaunchKernelGGL(k_wgrad_bf16_dma8, grid, dim3(2 * W_NT), 0, st, p);
     } else if (xh && gh) {
         hipLaunchKernelGGL((k_wgrad_bf16<true, true>), grid, dim3(W_NT), 0, st, p);
     } else if (xh) {

@@ -153,6 +153,30 @@ def sample_affine_bwd(gw, rho, eps):
     return gmu, grho
 
 
+def linear_bwd(mu, rho, x, gy, eps, shared_x=False, rounder=None):
+    """Gradients autograd derives through F.linear (nn/dense.py:60) and w = mu + sigma * eps
+    (nn/core.py:44-45) for S sampled weights, in float64 (examples/MNIST/train.py:63-65 is the caller):
+        dW_s = gy_s^T x_s;  g_mu = sum_s dW_s;  g_rho = sum_s dW_s * eps_s * sigmoid(rho);  gx_s = gy_s W_s.
+    eps: list of S arrays shaped like mu.  rounder (e.g. bf16_round) is applied to x, gy and W_s first
+    (the bf16 compute mode's operands).  -> (g_mu, g_rho, gx (S, M, K))."""
+    r = rounder or (lambda a: a)
+    mu = np.asarray(mu, np.float32)
+    rho = np.asarray(rho, np.float32)
+    g_mu = np.zeros(mu.shape, np.float64)
+    g_rho = np.zeros(mu.shape, np.float64)
+    gx = []
+    for s in range(len(eps)):
+        xs = r(np.asarray(x if shared_x else x[s], np.float32)).astype(np.float64)
+        g = r(np.asarray(gy[s], np.float32)).astype(np.float64)
+        w = r(sample_affine(mu, rho, eps[s])).astype(np.float64)
+        gw = g.T @ xs
+        dmu, drho = sample_affine_bwd(np.ones(mu.shape, np.float32), rho, eps[s])      # dw/dmu, dw/drho
+        g_mu += gw * dmu
+        g_rho += gw * drho
+        gx.append(g @ w)
+    return g_mu, g_rho, np.stack(gx)
+
+
 def kl_bwd(mu, rho, prior_mu, prior_sigma, scale):
     """orc_kl_bwd -- autograd of loss.py:28 times `scale`."""
     m, mp = _c(mu)

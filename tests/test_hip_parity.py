@@ -648,22 +648,9 @@ def _bwd_case(env, S, M, N, K, seed, shared_x=False):
     return mu, rho, x, gy, key, eps
 
 
-def _oracle_linear_bwd(orc, mu, rho, x, gy, eps, shared_x, rounder=lambda a: a):
-    """float64 restatement of autograd through F.linear (dense.py:60) and mu + sigma * eps (core.py:45)."""
-    S = gy.shape[0]
-    g_mu = np.zeros(mu.shape, np.float64)
-    g_rho = np.zeros(mu.shape, np.float64)
-    gx = []
-    for s in range(S):
-        xs = rounder(N(x if shared_x else x[s])).astype(np.float64)
-        g = rounder(N(gy[s])).astype(np.float64)
-        w = rounder(orc.sample_affine(N(mu), N(rho), eps[s])).astype(np.float64)
-        gw = g.T @ xs
-        a, b = orc.sample_affine_bwd(np.ones(mu.shape, np.float32), N(rho), eps[s])   # d w / d mu, d w / d rho
-        g_mu += gw * a
-        g_rho += gw * b
-        gx.append(g @ w)
-    return g_mu, g_rho, np.stack(gx)
+def _oracle_linear_bwd(orc, mu, rho, x, gy, eps, shared_x, rounder=None):
+    """oracle.linear_bwd: float64 restatement of autograd through F.linear (dense.py:60) and mu + sigma * eps (core.py:45)."""
+    return orc.linear_bwd(N(mu), N(rho), N(x), N(gy), eps, shared_x, rounder)
 
 
 BWD_SHAPES = [(1, 1, 1, 4), (2, 9, 6, 24), (3, 33, 10, 1200), (2, 70, 130, 260), (8, 64, 48, 136),
@@ -751,11 +738,11 @@ def test_bias_gradient_fused_into_weight_gradient(env, mode, M):
     n1 = env["lib"].bnn_launch_count()
     g_mu_w, g_rho_w, g_mu_b, g_rho_b = torch.autograd.grad(y, (md, rd, mbd, rbd), gy.to(dev).to(adt))
     assert env["lib"].bnn_launch_count() == n1 + 1            # ONE launch: weights and bias together
-    rnd = (lambda a: a) if mode == "f32" else orc.bf16_round
+    rnd = None if mode == "f32" else orc.bf16_round
     want_mu = np.zeros(Nn)
     want_rho = np.zeros(Nn)
     for s_ in range(S):
-        cs = rnd(N(gy[s_])).astype(np.float64).sum(0)
+        cs = (N(gy[s_]) if rnd is None else rnd(N(gy[s_]))).astype(np.float64).sum(0)
         eb = orc.eps_fill(kb.seed, kb.stream, s_, kb.epoch_host, 0, (Nn,))
         a, b = orc.sample_affine_bwd(np.ones(Nn, np.float32), N(rhob), eb)
         want_mu += cs * a

@@ -194,3 +194,17 @@ def test_flipout_conv_two_contractions(name, stride, pad):
     geo = dict(stride=(stride, stride), padding=(pad, pad))
     y = orc.conv2d(g["x"], g["mu_w"], None, **geo) + orc.conv2d(g["x"] * g["S"], orc.sigma(g["rho_w"]), None, **geo) * g["R"]
     assert allclose(y, g["y"])
+
+
+@pytest.mark.parametrize("name", ["linear_4x3", "linear_7x11_nobias", "linear_64x48"])
+def test_oracle_linear_bwd_matches_reference_autograd(name):
+    """oracle.linear_bwd (the checker of the HIP backward kernels) against the reference's own autograd
+    gradients of sum(y * gy) -- the KL part of the golden's loss is subtracted with oracle.kl_bwd."""
+    g = load_golden(name)
+    g_mu, g_rho, gx = orc.linear_bwd(g["mu_w"], g["rho_w"], g["x"][None], g["gy"][None], [g["eps_w"]])
+    ntens = 2 if "mu_b" in g else 1
+    km, kr = orc.kl_bwd(g["mu_w"], g["rho_w"], float(g["prior_mu"]), float(g["prior_sigma"]),
+                        1.0 / (g["mu_w"].size * ntens * float(g["n_batches"])))
+    assert np.allclose(g_mu + km, g["g_mu_w"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(g_rho + kr, g["g_rho_w"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(gx[0], g["g_x"], rtol=1e-4, atol=1e-5)
