@@ -107,10 +107,11 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 
     // NB chunk buffers: chunk c lives in buffer c % NB; with NB > 2 a wave may draw up to NB - 1
     // chunks ahead of the slowest consumer instead of meeting it at every chunk.
-    __shared__ __attribute__((aligned(16))) uint4 lds[A_WORDS + NB * B_CHUNK + (2 * NB + 3) / 4];
+    __shared__ __attribute__((aligned(16))) uint4 lds[A_WORDS + NB * B_CHUNK + (2 * NB + 3) / 4 + (BN + 3) / 4];
     uint4 *Bs0 = lds + A_WORDS;
     int *full = reinterpret_cast<int *>(lds + A_WORDS + NB * B_CHUNK);   // full[NB], then free[NB]
     int *freec = full + NB;
+    float *bias_lds = reinterpret_cast<float *>(lds + A_WORDS + NB * B_CHUNK + (2 * NB + 3) / 4);   // bias_lds[BN]
 
     unsigned long long *dbg = nullptr;
     int dbg_i = 0;
@@ -156,11 +157,21 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     const int k_lo = c_lo * (32 * CH);                  // absolute k of local chunk 0
 
     if (tid < 2 * NB) full[tid] = 0;
+    // the panel's BN bias values, drawn ONCE per workgroup (every wave needs all of them in its epilogue; per
+    // wave it was TN serial Philox blocks on every lane) -- ordered before all reads by the barrier below
+    if (p.mu_b != nullptr && tid < BN) {
+        const int n = n0 + tid;
+        float bv = 0.f;
+        if (n < p.N)
+            bv = fmaf(sigma_draw(p.rho_b[n]), eps1(p.rng_b, rng_epoch_dev(p.rng_b), (uint64_t)n, p.rng_b.sample0 + (uint32_t)s), p.mu_b[n]);
+        bias_lds[tid] = bv;
+    }
     __syncthreads();
 
     if constexpr (STAMPS) {
         if (p.dbg && (int)blockIdx.x == p.dbg_block && wave == 0) dbg = p.dbg;
     }
+    stamp(10);                                                      // kernel entry (after the LDS flag init barrier)
 
     // ---- draw side: this lane's unit of every chunk
     const uint32_t sample = p.rng_w.sample0 + (uint32_t)s;
@@ -427,15 +438,23 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     // prologue: draw chunks 0 .. LA-1, then put the queue in the state the top of iteration 0
     // expects: [R(LA), D(0) .. D(S-2)]
     if constexpr (LA == 2) {
-        // both chunks' (mu, rho) in flight at once: one memory round trip instead of two
-        fetch_unit(rawA, 0);
-        fetch_unit(rawB, 1);
-        wait_raw(rawA, std::integral_constant<int, LPU>{});
-        draw_unit(rawA, 0);                     // nch >= 1
+        // everything the first iterations need is put in flight at once -- the raw (mu, rho) of chunks 0, 1
+        // and LA, then the first S-1 A stages -- so the prologue pays ONE memory round trip; the queue ends
+        // in the state iteration 0 expects, [R(LA), D(0) .. D(S-2)]
+        Raw rawC;
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) rawC.r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fetch_unit(rawB, 0);
+        fetch_unit(rawC, 1);
+        fetch_unit(rawA, LA);
+#pragma unroll
+        for (int j = 0; j < S - 1; ++j) dma_A(j, j);
+        wait_raw(rawB, std::integral_constant<int, 2 * LPU + (S - 1) * PW>{});
+        draw_unit(rawB, 0);                     // nch >= 1
         publish(0);
-        wait_raw(rawB, std::integral_constant<int, 0>{});
+        wait_raw(rawC, std::integral_constant<int, LPU + (S - 1) * PW>{});
         if (1 < nch) {
-            draw_unit(rawB, 1);
+            draw_unit(rawC, 1);
             publish(1);
         }
     } else {
@@ -448,16 +467,18 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                 publish(c0);
             }
         }
-    }
-    fetch_unit(rawA, LA);
+        fetch_unit(rawA, LA);
 #pragma unroll
-    for (int j = 0; j < S - 1; ++j) dma_A(j, j);
+        for (int j = 0; j < S - 1; ++j) dma_A(j, j);
+    }
+    stamp(11);                                                      // prologue done
     for (int ch = 0; ch < nch; ch += 2) {
         iteration(ch, rawA, rawB);
         if (ch + 1 < nch) iteration(ch + 1, rawB, rawA);
     }
     // nothing may still be writing this workgroup's LDS when it retires
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(12);                                                      // loop done
 
     if constexpr (KS > 1) {
         // ---- split-K: publish this workgroup's partial tile, last arriver reduces (fixed order)
@@ -506,20 +527,59 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                 }
     }
 
-    // ---- epilogue: bias drawn per column, activation, store
-    uint32_t edev_b = 0;
+    // ---- epilogue: bias (drawn at kernel entry), activation, store
     const bool sampled_bias = (p.mu_b != nullptr);
-    if (sampled_bias) edev_b = rng_epoch_dev(p.rng_b);
     float *Yb = p.Y + (int64_t)s * p.y_sample_stride;
     uint16_t *Yh = reinterpret_cast<uint16_t *>(p.Y) + (int64_t)s * p.y_sample_stride;
     const bool y_bf16 = (p.flags & BNN_FLAG_Y_BF16) != 0;
+    // Full interior tiles with 16-B aligned rows: the wave's RW x BN results go through its own (now idle)
+    // A ring in LDS and leave as 16-B row chunks -- 3 (bf16) / 6 (fp32) wide stores per lane instead of
+    // 4 * TM * TN scattered 2- / 4-byte ones.  Everything else takes the element-wise path below.
+    {
+        const int esz = y_bf16 ? 2 : 4;
+        const int64_t ybase = (int64_t)s * p.y_sample_stride * esz;
+        const bool wide = !(p.flags & kFlagStoreNCHW) && n0 + BN <= p.N && m0 + wave * RW + RW <= p.M &&
+                          (p.ldy * esz) % 16 == 0 && ((reinterpret_cast<uintptr_t>(p.Y) + ybase) & 15u) == 0 && (n0 * esz) % 16 == 0;
+        static_assert(S * A_STAGE * 16 >= RW * BN * 4, "the wave's A ring must hold its output tile");
+        if (wide) {
+            char *T = reinterpret_cast<char *>(Aw);
+            const int pitch = BN * esz;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                float bias = 0.f;
+                if (sampled_bias) bias = bias_lds[b * 16 + fi];
+                else if (p.bias) bias = p.bias[(int64_t)s * p.bias_sample_stride + n0 + b * 16 + fi];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[a][b][r] + bias;
+                        if (p.flags & BNN_FLAG_RELU) v = fmaxf(v, 0.f);
+                        char *q = T + (a * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * esz;
+                        if (y_bf16) *reinterpret_cast<uint16_t *>(q) = f2bf(v);
+                        else *reinterpret_cast<float *>(q) = v;
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // this wave's ds_writes before its ds_reads
+            __builtin_amdgcn_wave_barrier();
+            const int cpr = pitch / 16;                              // 16-B chunks per row
+            char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)(m0 + wave * RW) * p.ldy + n0) * esz;
+            for (int c = lane; c < RW * cpr; c += 64) {
+                const int row = c / cpr, cc = c % cpr;
+                *reinterpret_cast<uint4 *>(Y8 + (int64_t)row * p.ldy * esz + cc * 16) = *reinterpret_cast<const uint4 *>(T + row * pitch + cc * 16);
+            }
+            if constexpr (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            stamp(13);
+            return;
+        }
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + b * 16 + fi;
         if (n >= p.N) continue;
         float bias = 0.f;
         if (sampled_bias)
-            bias = fmaf(sigma_draw(p.rho_b[n]), eps1(p.rng_b, edev_b, (uint64_t)n, p.rng_b.sample0 + (uint32_t)s), p.mu_b[n]);
+            bias = bias_lds[b * 16 + fi];
         else if (p.bias)
             bias = p.bias[(int64_t)s * p.bias_sample_stride + n];
 #pragma unroll
@@ -551,6 +611,8 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
             }
         }
     }
+    if constexpr (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    stamp(13);                                                      // epilogue stores retired
 }
 
 template <int NW, int RW, int BN, int CH, int S, int NB, int BMODE, int CP, bool ABF = false, int KS = 1>

@@ -34,3 +34,8 @@ for name, base in (("wave 0", 0),):
     for k in sorted(acc):
         v = acc[k]
         print("   %3d -> %3d : n=%3d  mean %8.0f  min %6d  max %7d  sum %9d" % (k[0], k[1], len(v), sum(v) / len(v), min(v), max(v), sum(v)))
+
+    marks = {t: c for t, c in rows if t >= 10}
+    if 10 in marks and 13 in marks:
+        print("   timeline (ticks): entry->prologue %d, prologue->loop end %d, loop end->stores retired %d, total %d" % (
+            marks[11] - marks[10], marks[12] - marks[11], marks[13] - marks[12], marks[13] - marks[10]))
