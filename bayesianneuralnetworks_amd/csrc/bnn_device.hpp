@@ -72,9 +72,11 @@ __device__ __forceinline__ uint32_t rng_epoch_dev(const RngDev &r)
     return e + (uint32_t)r.epoch_dev_delta;
 }
 
+// u = ((x >> 8) + 0.5) * 2^-24 in (0, 1), as ONE fma: a 2^-24 + 2^-25 is the same real number rounded once
+// (the two-instruction form rounds a + 0.5 and then scales by a power of two, which is exact) -- bit-identical.
 __device__ __forceinline__ float u01(uint32_t x)
 {
-    return ((float)(x >> 8) + 0.5f) * 0x1p-24f;
+    return __builtin_fmaf((float)(x >> 8), 0x1p-24f, 0x1p-25f);
 }
 
 // One Box-Muller pair.  v_sin_f32 / v_cos_f32 take their argument in revolutions,
@@ -131,8 +133,8 @@ __device__ __forceinline__ float eps1(const RngDev &r, uint32_t epoch_dev, uint6
 __device__ __forceinline__ float sigma_draw(float rho)
 {
     const float e = __builtin_amdgcn_exp2f(rho * 1.44269504088896341f);
-    const float sp = __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f;
-    return 1e-10f + (rho > 20.0f ? rho : sp);
+    const float sp = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), 0.693147180559945309f, 1e-10f);
+    return rho > 20.0f ? rho : sp;                 // (rho + 1e-10 == rho in fp32 above the threshold)
 }
 
 // Same value to ~1e-6 RELATIVE accuracy (used where ln(sigma) is taken: KL, and for
