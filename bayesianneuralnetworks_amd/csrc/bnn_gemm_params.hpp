@@ -38,6 +38,7 @@ struct GemmParams {
     int32_t M, N, K;
     int32_t S, G;
     int32_t ntn, ntm;           // tiles
+    int32_t xcd_a;              // > 0: 2-D XCD map, xcd_a sample groups x (8 / xcd_a) panel groups (bnn_linear.hip)
     int32_t flags;
     int32_t vecA, vecB;         // 16-B loads legal
     RngDev rng_w, rng_b;

@@ -133,7 +133,22 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     {
         const int per_s = p.ntn * p.ntm;
         int rem;
-        if (p.S % 8 == 0) {
+        if (KS == 1 && p.xcd_a > 0) {
+            // 2-D XCD map: XCD (blockIdx % 8) = (sample group, panel group).  One XCD's L2 then holds 1/xb of
+            // mu / rho and 1/xa of the activations instead of ALL of mu / rho (sample -> XCD): fabric traffic
+            // of layer 2 falls from 8 x 11.5 + 9.8 MB to 8 x (2.9 + 4.9) MB.  The grid is padded to the largest
+            // XCD share; surplus workgroups leave at once (before any barrier).
+            const int xa = p.xcd_a, xb = 8 / xa;
+            const int xcd = L & 7, idx = L >> 3;
+            const int sg = xcd % xa, pg = xcd / xa;
+            const int spg = p.S / xa, ppg = (p.ntn + xb - 1) / xb;
+            const int s_l = idx / (ppg * p.ntm), r2 = idx % (ppg * p.ntm);
+            s = sg * spg + s_l;
+            panel = pg * ppg + r2 / p.ntm;
+            mt = r2 % p.ntm;
+            if (s_l >= spg || panel >= p.ntn) return;
+            rem = panel * p.ntm + mt;
+        } else if (p.S % 8 == 0) {
             const int i_in = L >> 3;            // MC sample -> XCD (blockIdx % 8)
             s = (L & 7) + 8 * (i_in / per_s);
             rem = i_in % per_s;
@@ -621,7 +636,30 @@ static void launch_sym(GemmParams &p, hipStream_t st)
     constexpr int BM = NW * RW;
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = (p.N + BN - 1) / BN;
-    const int64_t grid = (int64_t)p.ntn * p.ntm * p.S * KS;
+    int64_t grid = (int64_t)p.ntn * p.ntm * p.S * KS;
+    p.xcd_a = 0;
+    if (KS == 1 && p.S % 8 == 0 && p.ntn >= 8) {
+        // choose the XCD grid (xa sample groups x 8/xa panel groups) with the least L2 fill per XCD:
+        // weights / xb + activations / xa (a shared input counts once whatever xa is)
+        static const int force = [] { const char *e = getenv("BNN_XCD_A"); return e ? atoi(e) : -1; }();
+        const double wbytes = 8.0 * p.N * p.K * (BMODE == B_PLAIN ? 0.5 * p.S : 1.0);
+        const double abytes = (double)p.M * p.K * (ABF ? 2 : 4) * (p.a_sample_stride == 0 ? 1 : p.S);
+        int best = 8;
+        double best_cost = 1e300;
+        for (int xa = 1; xa <= 8; xa *= 2) {
+            const int xb = 8 / xa, ppg = (p.ntn + xb - 1) / xb;
+            const double pad = (double)(p.S / xa) * ppg * 8 / ((double)p.S * p.ntn);
+            if (pad > 1.2) continue;                                // too many idle workgroup slots
+            const double cost = wbytes / xb + (p.a_sample_stride == 0 ? abytes : abytes / xa);
+            if (cost < best_cost) { best_cost = cost; best = xa; }
+        }
+        if (force >= 0) best = force;
+        if (best >= 1 && best < 8 && 8 % best == 0 && p.S % best == 0) {
+            p.xcd_a = best;
+            const int xb = 8 / best, ppg = (p.ntn + xb - 1) / xb;
+            grid = (int64_t)8 * (p.S / best) * ppg * p.ntm;
+        }
+    }
     if constexpr (KS > 1) {
         hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, ABF, false, KS>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
         return;
