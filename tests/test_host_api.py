@@ -229,3 +229,25 @@ def test_mc_batched_is_opt_in_and_cpu_uses_the_serial_loop():
     ys = net(torch.ones(2, 3), samples=3)
     assert isinstance(ys, list) and len(ys) == 3
     assert isinstance(net(torch.ones(2, 3)), torch.Tensor)
+
+
+def test_training_callers_refuse_cpu_tensors_loudly():
+    """optim.Adam / ops.cross_entropy / the backward entry points exist only as HIP: no CPU fallback."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd import ops, optim
+    from bayesianneuralnetworks_amd._lib import BnnHipError
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.ones(3)
+    with pytest.raises(BnnHipError):
+        optim.Adam([p]).step()
+    with pytest.raises(ValueError):
+        optim.Adam([p], lr=-1.0)
+    with pytest.raises(BnnHipError):
+        ops.cross_entropy(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long))
+    assert bnn.optim.Adam is optim.Adam
+
+
+def test_gradient_reducer_rejects_non_fp32_parameters():
+    from bayesianneuralnetworks_amd import distributed as bd
+    with pytest.raises(TypeError):
+        bd.GradAllReducer([torch.nn.Parameter(torch.ones(2, dtype=torch.float64))])
