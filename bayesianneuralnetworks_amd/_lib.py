@@ -47,6 +47,13 @@ class AdamTensor(ctypes.Structure):
                 ("n", ctypes.c_int64)]
 
 
+class KlFuse(ctypes.Structure):
+    """bnn_kl_fuse_t"""
+    _fields_ = [("upstream", ctypes.c_void_p), ("mu_w", ctypes.c_void_p), ("mu_b", ctypes.c_void_p),
+                ("scale_w", ctypes.c_float), ("prior_mu_w", ctypes.c_float), ("prior_sigma_w", ctypes.c_float),
+                ("scale_b", ctypes.c_float), ("prior_mu_b", ctypes.c_float), ("prior_sigma_b", ctypes.c_float)]
+
+
 class Conv2dShape(ctypes.Structure):
     """bnn_conv2d_shape_t"""
     _fields_ = [(n, ctypes.c_int32) for n in
@@ -85,7 +92,7 @@ SIGNATURES = {
                                                  _rngp, _int, _int, _p]),
     "bnn_linear_backward_input": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p]),
     "bnn_linear_backward_weight_sampled": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64,
-                                                  _i64, _int, _rngp, _rngp, _int, _int, _int, _p]),
+                                                  _i64, _int, _rngp, _rngp, ctypes.POINTER(KlFuse), _int, _int, _int, _p]),
     "bnn_linear_backward_weight": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _int,
                                           _int, _int, _p]),
     "bnn_colsum": (_int, [_p, _i64, _i64, _p, _i64, _i64, _int, _int, _p]),

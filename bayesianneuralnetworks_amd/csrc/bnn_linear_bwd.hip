@@ -50,6 +50,11 @@ struct WgradParams {
     const float *rho_b;
     float *g_mu_b, *g_rho_b;
     RngDev rng_b;
+    // optional fused KL gradient (the closed form of bnn_kl_backward, added in the final store):
+    //   g_mu += c (mu - mu_p) / sigma_p^2,  g_rho += c (sigma / sigma_p^2 - 1 / sigma) sigmoid(rho),  c = *kl_up * kl_scale
+    const float *kl_up;         // device scalar (the upstream gradient of the KL term); NULL = no KL
+    const float *mu_w, *mu_b;   // posterior means (the KL gradient needs them; the likelihood gradient does not)
+    float kl_scale_w, kl_pm_w, kl_ps_w, kl_scale_b, kl_pm_b, kl_ps_b;
 };
 
 constexpr int W_TK = 128, W_TN = 64, W_BM = 32, W_NT = 256;
@@ -135,6 +140,16 @@ struct WgradAcc {
     f32x4 acc[4][2], gmu[4][2], grho[4][2];
 };
 
+// Closed-form d KL(N(mu, sigma(rho)^2) || N(pm, ps^2)) / d (mu, rho) times c, as in bnn_kl.hip:k_kl_backward;
+// the rho part is returned BEFORE the sigmoid(rho) factor the callers apply to the whole sum.
+__device__ __forceinline__ void kl_grad_terms(float mu, float rho, float c, float pm, float ps, float &dmu, float &drho_pre)
+{
+    const float inv_ps2 = 1.0f / (ps * ps);
+    const float sg = sigma_accurate(rho);
+    dmu = c * (mu - pm) * inv_ps2;
+    drho_pre = c * (sg * inv_ps2 - 1.0f / sg);
+}
+
 // Fused bias gradient.  Each of the 4 waves of a k-tile-0 workgroup takes ONE 16-column subtile (wave (wk, wn):
 // columns nb + 16 wk ..), so the extra MFMA per step is spread evenly.  cs = running column sums of gy over the
 // current sample (every row of the MFMA result is the same sum; row 0 = lanes 0..15, element 0, is used).
@@ -166,7 +181,15 @@ __device__ __forceinline__ void wgrad_bias_store(const WgradBias &Bz, const Wgra
     const int lane = threadIdx.x & 63;
     const int n = nbias + lane;
     if (lane >= 16 || n >= p.N) return;
-    float gm = Bz.gmu, gr = Bz.grho * dsoftplus(p.rho_b[n]);
+    float gm = Bz.gmu, gr = Bz.grho;
+    const float rb = p.rho_b[n];
+    if (p.kl_up && p.mu_b) {
+        float dm, dr;
+        kl_grad_terms(p.mu_b[n], rb, p.kl_up[0] * p.kl_scale_b, p.kl_pm_b, p.kl_ps_b, dm, dr);
+        gm += dm;
+        gr += dr;
+    }
+    gr *= dsoftplus(rb);
     if (p.accumulate) { gm += p.g_mu_b[n]; gr += p.g_rho_b[n]; }
     p.g_mu_b[n] = gm;
     p.g_rho_b[n] = gr;
@@ -255,7 +278,14 @@ __device__ __forceinline__ void wgrad_store(const WgradAcc &A, const WgradParams
             for (int r = 0; r < 4; ++r) {
                 if (k + r >= p.K) continue;
                 if (final_pass) {
-                    gr[r] *= dsoftplus(p.rho[e0 + r]);
+                    const float rw = p.rho[e0 + r];
+                    if (p.kl_up) {
+                        float dm, dr;
+                        kl_grad_terms(p.mu_w[e0 + r], rw, p.kl_up[0] * p.kl_scale_w, p.kl_pm_w, p.kl_ps_w, dm, dr);
+                        gm[r] += dm;
+                        gr[r] += dr;
+                    }
+                    gr[r] *= dsoftplus(rw);
                     if (p.accumulate) { gm[r] += om[e0 + r]; gr[r] += orho[e0 + r]; }
                 } else if (p.plain && p.accumulate) {
                     gm[r] += om[e0 + r];
@@ -805,7 +835,9 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_f32(const WgradParams p)
 // Fixed-order sum of the sample-group partials (nsplit > 1), then sigmoid(rho) on the rho part.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ slabs, int64_t slab_stride, int nsplit,
                                                       const float *__restrict__ rho, float *__restrict__ g_mu,
-                                                      float *__restrict__ g_rho, int64_t n, int accumulate)
+                                                      float *__restrict__ g_rho, int64_t n, int accumulate,
+                                                      const float *__restrict__ kl_up, const float *__restrict__ mu,
+                                                      float kl_scale, float kl_pm, float kl_ps)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
@@ -813,6 +845,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     for (int g = 0; g < nsplit; ++g) {
         gm += slabs[(int64_t)g * slab_stride + e];
         gr += slabs[(int64_t)g * slab_stride + n + e];
+    }
+    if (kl_up) {
+        float dm, dr;
+        kl_grad_terms(mu[e], rho[e], kl_up[0] * kl_scale, kl_pm, kl_ps, dm, dr);
+        gm += dm;
+        gr += dr;
     }
     gr *= dsoftplus(rho[e]);
     if (accumulate) { gm += g_mu[e]; gr += g_rho[e]; }
@@ -1012,9 +1050,13 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
                                        const float *rho_w, float *g_mu, float *g_rho, const float *rho_b,
                                        float *g_mu_b, float *g_rho_b, int64_t M, int64_t N,
                                        int64_t K, int nsamples, const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
-                                       int compute, int flags, int accumulate, void *stream)
+                                       const bnn_kl_fuse_t *kl, int compute, int flags, int accumulate, void *stream)
 {
     const char *who = "bnn_linear_backward_weight_sampled";
+    if (kl && (!kl->upstream || !kl->mu_w || !(kl->prior_sigma_w > 0.f) || (kl->mu_b && !(kl->prior_sigma_b > 0.f)))) {
+        set_error("%s: kl needs upstream, mu_w and positive prior sigmas", who);
+        return BNN_E_NULL;
+    }
     if (!x || !gy || !rho_w || !g_mu || !g_rho) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     const bool want_bias = rho_b || g_mu_b || g_rho_b;
     if (want_bias && (!rho_b || !g_mu_b || !g_rho_b || !rng_b)) { set_error("%s: rho_b, g_mu_b, g_rho_b, rng_b must be given together", who); return BNN_E_NULL; }
@@ -1068,10 +1110,21 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
             float *tmp = ws.ws_slabs + (int64_t)p.nsplit * p.slab_stride;
             rc = bnn_colsum(gy, gy_sample_stride, ldgy, tmp, M, N, nsamples, gh ? BNN_FLAG_X_BF16 : 0, stream);
             if (!rc) rc = bnn_sample_affine_bwd(tmp, N, rho_b, nullptr, 0, rng_b, N, nsamples, g_mu_b, g_rho_b, accumulate, stream);
+            if (!rc && kl && kl->mu_b) {
+                // bias KL gradient on top (one tensor; scale_b already folds 1 / (n_b * T * n_batches))
+                const bnn_kl_tensor_t kt = {kl->mu_b, rho_b, N, kl->prior_mu_b, kl->prior_sigma_b};
+                float *gmp[1] = {g_mu_b}, *grp[1] = {g_rho_b};
+                rc = bnn_kl_backward(&kt, 1, 1.0f / (kl->scale_b * (float)N), kl->upstream, gmp, grp, 1, stream);
+            }
             if (rc) return rc;
         }
     } else if (want_bias) {
         p.rho_b = rho_b; p.g_mu_b = g_mu_b; p.g_rho_b = g_rho_b; p.rng_b = make_rng(rng_b);
+    }
+    if (kl) {
+        p.kl_up = kl->upstream; p.mu_w = kl->mu_w; p.mu_b = want_bias ? kl->mu_b : nullptr;
+        p.kl_scale_w = kl->scale_w; p.kl_pm_w = kl->prior_mu_w; p.kl_ps_w = kl->prior_sigma_w;
+        p.kl_scale_b = kl->scale_b; p.kl_pm_b = kl->prior_mu_b; p.kl_ps_b = kl->prior_sigma_b;
     }
     // diagnostic only (timing split of the loop vs the eps epilogue; results are then NOT the gradient)
     static const bool diag_noeps = [] { const char *e = getenv("BNN_WGRAD_NOEPS"); return e && e[0] == '1'; }();
@@ -1099,7 +1152,8 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
     if (rc || p.nsplit == 1) return rc;
     const int64_t n = N * K;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws.ws_slabs, p.slab_stride,
-                       p.nsplit, rho_w, g_mu, g_rho, n, accumulate);
+                       p.nsplit, rho_w, g_mu, g_rho, n, accumulate, kl ? kl->upstream : nullptr, kl ? kl->mu_w : nullptr,
+                       kl ? kl->scale_w : 0.f, kl ? kl->prior_mu_w : 0.f, kl ? kl->prior_sigma_w : 1.f);
     return check_launch(who);
 }
 

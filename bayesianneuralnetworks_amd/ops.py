@@ -151,6 +151,64 @@ def _bf(t):
     return t.dtype == torch.bfloat16
 
 
+# --- KL gradient fused into the weight-gradient launch ------------------------------------------------
+# KLDivergence's backward does not compute its gradient when the parameter's layer can do it for free: it
+# PARKS (upstream, scale, prior) per posterior tensor here, keyed by the mean's storage; the sampled linear /
+# conv backward of that layer -- which runs later in the same backward pass -- picks the entry up and the
+# weight-gradient kernel adds the closed-form KL gradient in its final store (no bnn_kl_backward pass, no
+# autograd accumulation add per parameter).  Entries nobody picked up (parity-mode layers, unused layers, a
+# KL node that happened to run after the layers) are flushed at the end of the pass by an engine callback.
+FUSE_KL_GRADIENT = True
+_kl_pending = {}
+
+
+class _KlPending:
+    __slots__ = ("up", "scale", "prior", "mu", "rho")
+
+    def __init__(self, up, scale, prior, mu, rho):
+        self.up, self.scale, self.prior, self.mu, self.rho = up, scale, prior, mu, rho
+
+
+def _kl_take(mu):
+    return _kl_pending.pop((mu.device.index, mu.data_ptr()), None) if _kl_pending else None
+
+
+def _kl_fuse_struct(ent_w, ent_b):
+    """bnn_kl_fuse_t for a layer whose weight entry (and optionally bias entry) were parked by the same KL node."""
+    k = _lib.KlFuse()
+    k.upstream = ent_w.up.data_ptr()
+    k.mu_w = ent_w.mu.data_ptr()
+    k.scale_w, k.prior_mu_w, k.prior_sigma_w = ent_w.scale, ent_w.prior[0], ent_w.prior[1]
+    if ent_b is not None:
+        k.mu_b = ent_b.mu.data_ptr()
+        k.scale_b, k.prior_mu_b, k.prior_sigma_b = ent_b.scale, ent_b.prior[0], ent_b.prior[1]
+    else:
+        k.mu_b, k.scale_b, k.prior_mu_b, k.prior_sigma_b = None, 0.0, 0.0, 1.0
+    return k
+
+
+def _kl_flush():
+    """Engine callback at the end of a backward pass: KL gradients of the tensors no layer picked up."""
+    if not _kl_pending:
+        return
+    ents = list(_kl_pending.values())
+    _kl_pending.clear()
+    lib = _lib.load()
+    for e in ents:
+        g_mu, g_rho = torch.empty_like(e.mu), torch.empty_like(e.rho)
+        arr = _kl_descs([e.mu], [e.rho], [e.prior])
+        gm = (ctypes.c_void_p * 1)(g_mu.data_ptr())
+        gr = (ctypes.c_void_p * 1)(g_rho.data_ptr())
+        # scale = 1 / (n * T * n_batches): hand bnn_kl_backward an n_batches that reproduces it for one tensor
+        check(lib.bnn_kl_backward(arr, 1, 1.0 / (e.scale * e.mu.numel()), ptr(e.up), gm, gr, 0, stream_ptr(e.mu.device)),
+              "bnn_kl_backward")
+        for p_, g_ in ((e.mu, g_mu), (e.rho, g_rho)):
+            if p_.grad is None:
+                p_.grad = g_
+            else:
+                p_.grad.add_(g_)
+
+
 def _relu_backward_raw(g, y):
     """g * (y > 0) (the fused ReLU epilogue's backward)."""
     out = torch.empty_like(g)
@@ -213,13 +271,13 @@ class _SampledLinear(torch.autograd.Function):
             raise BnnHipError("linear: input has %d features, weight expects %d" % (K, mu_w.shape[1]))
         y = _linear_sampled_raw(x, 0 if shared_x else M * K, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b,
                                 compute, relu, out_dtype)
-        ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None, y if relu else None)
+        ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None, y if relu else None, mu_b)
         ctx.key_w, ctx.key_b, ctx.shared_x, ctx.compute = key_w, key_b, shared_x, compute
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, mu_w, rho_w, rho_b, y_relu = ctx.saved_tensors
+        x, mu_w, rho_w, rho_b, y_relu, mu_b = ctx.saved_tensors
         S, compute = ctx.key_w.nsamples, ctx.compute
         N, K = mu_w.shape
         M = x.shape[-2]
@@ -260,11 +318,16 @@ class _SampledLinear(torch.autograd.Function):
                 g_mu_b = torch.empty_like(rho_b)
                 g_rho_b = torch.empty_like(rho_b)
                 rb = _rng_struct(ctx.key_b, dev)
+            # ... and so does the KL gradient, when KLDivergence's backward parked it for this layer
+            ent_w = _kl_take(mu_w)
+            ent_b = _kl_take(mu_b) if (ent_w is not None and need_b and mu_b is not None) else None
+            kl = _kl_fuse_struct(ent_w, ent_b) if ent_w is not None else None
             check(lib.bnn_linear_backward_weight_sampled(ptr(x), 0 if ctx.shared_x else M * K, K, ptr(gy), M * N, N,
                                                          ptr(rho_w), ptr(g_mu_w), ptr(g_rho_w),
                                                          ptr(rho_b) if need_b else None, ptr(g_mu_b), ptr(g_rho_b),
                                                          M, N, K, S, ctypes.byref(rw),
                                                          ctypes.byref(rb) if rb is not None else None,
+                                                         ctypes.byref(kl) if kl is not None else None,
                                                          compute, flags, 0, stream_ptr(dev)),
                   "bnn_linear_backward_weight_sampled")
         elif need_b:
@@ -447,11 +510,14 @@ class _SampledConv2d(torch.autograd.Function):
                 g_mu_b = torch.empty_like(rho_b)
                 g_rho_b = torch.empty_like(rho_b)
                 rb = _rng_struct(ctx.key_b, dev)
+            ent_w = _kl_take(mu_w)
+            kl = _kl_fuse_struct(ent_w, None) if ent_w is not None else None    # (a conv bias entry is left to the flush)
             check(lib.bnn_linear_backward_weight_sampled(ptr(panel), 0 if ctx.shared_x else M * K, K, ptr(rows), M * O, O,
                                                          ptr(rho_w), ptr(g_mu_w), ptr(g_rho_w),
                                                          ptr(rho_b) if need_b else None, ptr(g_mu_b), ptr(g_rho_b),
                                                          M, O, K, S, ctypes.byref(rw),
                                                          ctypes.byref(rb) if rb is not None else None,
+                                                         ctypes.byref(kl) if kl is not None else None,
                                                          compute, aflag | (_lib.FLAG_Y_BF16 if bf else 0), 0, st),
                   "bnn_linear_backward_weight_sampled")
             need_b = False
@@ -593,6 +659,13 @@ class _KLNormal(torch.autograd.Function):
         T = ctx.T
         mus, rhos = params[:T], params[T:]
         up = g_out[T:T + 1].contiguous()
+        if FUSE_KL_GRADIENT and all(m.is_leaf and r.is_leaf for m, r in zip(mus, rhos)) and \
+                not any((m.device.index, m.data_ptr()) in _kl_pending for m in mus):       # (two KL terms on one tensor: no parking)
+            # park the gradient for the layers' weight-gradient launches (see _kl_pending above)
+            for m, r, pr in zip(mus, rhos, ctx.priors):
+                _kl_pending[(m.device.index, m.data_ptr())] = _KlPending(up, 1.0 / (m.numel() * T * ctx.n_batches), pr, m, r)
+            torch.autograd.Variable._execution_engine.queue_callback(_kl_flush)
+            return (None, None, None) + (None,) * (2 * T)
         g_mu = [torch.empty_like(m) for m in mus]
         g_rho = [torch.empty_like(r) for r in rhos]
         arr = _kl_descs(mus, rhos, ctx.priors)

@@ -213,13 +213,25 @@ int bnn_linear_backward_input(const void *gy, int64_t gy_sample_stride, int64_t 
  * Bias (rho_b, g_mu_b, g_rho_b, rng_b all given, or all NULL): g_mu_b[n] (+)= sum_s c_s[n],
  * g_rho_b[n] (+)= sum_s c_s[n] * eps_b,s[n] * sigmoid(rho_b[n]), c_s = column sums of gy[s] -- taken
  * inside the same launch by the workgroups of k-tile 0 (one extra MFMA against a fragment of ones per
- * step), or by bnn_colsum + bnn_sample_affine_bwd when the samples are split. */
+ * step), or by bnn_colsum + bnn_sample_affine_bwd when the samples are split.
+ * KL (kl != NULL): the gradient of the layer's share of KLDivergence (loss.py:16-38) is added in the
+ * same final store -- g_mu += c (mu - mu_p) / sigma_p^2, g_rho += c (sigma / sigma_p^2 - 1 / sigma)
+ * sigmoid(rho), c = *upstream * scale -- instead of a separate bnn_kl_backward pass plus autograd's
+ * accumulation adds.  scale_x = 1 / (n_x * ntensors * n_batches), n_x = elements of that tensor. */
+typedef struct bnn_kl_fuse {
+    const float *upstream;      /* device scalar: d loss / d KL */
+    const float *mu_w;          /* (N, K) */
+    const float *mu_b;          /* (N) or NULL */
+    float scale_w, prior_mu_w, prior_sigma_w;
+    float scale_b, prior_mu_b, prior_sigma_b;
+} bnn_kl_fuse_t;
 int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
                                        const void *gy, int64_t gy_sample_stride, int64_t ldgy,
                                        const float *rho_w, float *g_mu, float *g_rho,
                                        const float *rho_b, float *g_mu_b, float *g_rho_b,
                                        int64_t M, int64_t N, int64_t K, int nsamples,
                                        const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
+                                       const bnn_kl_fuse_t *kl,
                                        int compute, int flags, int accumulate, void *stream);
 /* F.linear's own weight gradient, per sample: gw[s][n][k] (+)= sum_m gy[s][m][n] * x[s][m][k],
  * gw[s] = gw + s * gw_sample_stride (parity mode, where the draw is a separate op). */

@@ -793,7 +793,7 @@ def test_weight_gradient_is_bitwise_reproducible_and_accumulates(env):
             gr = torch.full((Nn, K), 2.0, device=dev)
             _lib.check(env["lib"].bnn_linear_backward_weight_sampled(
                 _lib.ptr(xd), M * K, K, _lib.ptr(gyd), M * Nn, Nn, _lib.ptr(rhod), _lib.ptr(gm), _lib.ptr(gr), None, None, None,
-                M, Nn, K, S, ctypes.byref(r), None, _lib.COMPUTE_F32, 0, acc, _lib.stream_ptr(dev)), "wgrad")
+                M, Nn, K, S, ctypes.byref(r), None, None, _lib.COMPUTE_F32, 0, acc, _lib.stream_ptr(dev)), "wgrad")
             outs.append((gm, gr))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         assert torch.allclose(outs[2][0], outs[0][0] + 1.0, rtol=1e-6, atol=1e-6)

@@ -23,7 +23,7 @@ for it in range(iters + 3):
     if it == 3:
         e0.record()
     _lib.check(lib.bnn_linear_backward_weight_sampled(_lib.ptr(x), M * K, K, _lib.ptr(gy), M * N, N, _lib.ptr(rho), _lib.ptr(gm),
-                                                      _lib.ptr(gr), None, None, None, M, N, K, S, ctypes.byref(kw), None, comp, flags, 0, st), "wgrad")
+                                                      _lib.ptr(gr), None, None, None, M, N, K, S, ctypes.byref(kw), None, None, comp, flags, 0, st), "wgrad")
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / iters * 1e3
