@@ -916,6 +916,57 @@ def test_softmax_cross_entropy_matches_torch(env):
         assert torch.allclose(x.grad, xr.grad, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_training_loop_learns_a_separable_task(env, mode):
+    """The reference's loop body (examples/MNIST/train.py:53-65) end to end on the device -- MC-batched
+    forward, fused ReLU / bf16 activations, KLDivergence, HIP cross-entropy, HIP backward with the KL
+    gradient folded into the weight-gradient launch, HIP Adam: a linearly separable 3-class task is
+    learnt (loss falls, accuracy > 95 %), and the posterior scales move (the KL / draw-backward path)."""
+    from bayesianneuralnetworks_amd import optim
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule, KLDivergence, fuse_activations
+    dev = env["dev"]
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(16, 3, 4)
+            self.layers = torch.nn.Sequential(NormalLinear(16, 64), torch.nn.ReLU(), NormalLinear(64, 3))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    torch.manual_seed(0)
+    env["bnn"].manual_seed(0)
+    env["bnn"].set_compute(mode)
+    try:
+        net = Net().to(dev)
+        net.mc_batched = True
+        fuse_activations(net, bf16_activations=(mode == "bf16"))
+        gen = torch.Generator().manual_seed(4)
+        centers = torch.randn(3, 16, generator=gen) * 3
+        y = torch.randint(0, 3, (512,), generator=gen)
+        x = (centers[y] + torch.randn(512, 16, generator=gen)).to(dev)
+        y = y.to(dev)
+        kld = KLDivergence(number_of_batches=50)
+        opt = optim.Adam(net.parameters(), lr=5e-3)
+        rho0 = net.layers[0].weight.scale.detach().clone()
+        losses = []
+        for step in range(120):
+            opt.zero_grad(set_to_none=True)
+            ys = net.forward_stacked(x, 4)                                  # (4, 512, 3)
+            loss = env["ops"].cross_entropy(ys.reshape(4 * 512, 3).float(), y.repeat(4)) + kld(net)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        with torch.no_grad():
+            pred = net.forward_stacked(x, 4).float().mean(0).argmax(-1)
+        assert losses[-1] < 0.5 * losses[0]
+        assert (pred == y).float().mean().item() > 0.95
+        assert (net.layers[0].weight.scale.detach() - rho0).abs().max().item() > 1e-3
+        assert all(torch.isfinite(p).all() for p in net.parameters())
+    finally:
+        env["bnn"].set_compute("f32")
+
+
 # ------------------------------------------------------------------ properties at full size
 def test_full_size_linearity_property(env):
     """BASELINE size (512 x 1200 x 1200): with the draw frozen (sample=False) and no bias the
