@@ -397,6 +397,7 @@ static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
                          int nsamples, const bnn_rng_t *rng_w, const bnn_rng_t *rng_b, bool sampled,
                          int compute, int flags, void *stream, const char *who)
 {
+    if (M == 0 && N >= 1 && K >= 1 && nsamples >= 1) return BNN_OK;     // empty batch: nothing to do (x / y may be NULL)
     if (!x || !y || (sampled ? (!mu_w || !rho_w) : !w)) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (sampled && ((mu_b == nullptr) != (rho_b == nullptr))) { set_error("%s: mu_b / rho_b must both be given or both NULL", who); return BNN_E_NULL; }
     if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldy < N) { set_error("%s: bad extent (M=%lld N=%lld K=%lld S=%d ldx=%lld ldy=%lld)", who, (long long)M, (long long)N, (long long)K, nsamples, (long long)ldx, (long long)ldy); return BNN_E_SHAPE; }
@@ -641,6 +642,7 @@ int bnn_linear_backward_input_sampled(const void *gy, int64_t gy_sample_stride, 
                                       int nsamples, const bnn_rng_t *rng_w, int compute, int flags, void *stream)
 {
     const char *who = "bnn_linear_backward_input_sampled";
+    if (M == 0 && N >= 1 && K >= 1 && nsamples >= 1) return BNN_OK;     // empty batch
     if (!gy || !mu_w || !rho_w || !gx) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldgy < N || ldgx < K) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
     if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF || N * K > ((int64_t)1 << 34)) { set_error("%s: extent too large", who); return BNN_E_RANGE; }

@@ -1053,6 +1053,8 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
                                        const bnn_kl_fuse_t *kl, int compute, int flags, int accumulate, void *stream)
 {
     const char *who = "bnn_linear_backward_weight_sampled";
+    if (M == 0 && !x) x = rho_w;                                    // empty batch: the operands are never read,
+    if (M == 0 && !gy) gy = rho_w;                                  // only the zero / accumulate path below runs
     if (kl && (!kl->upstream || !kl->mu_w || !(kl->prior_sigma_w > 0.f) || (kl->mu_b && !(kl->prior_sigma_b > 0.f)))) {
         set_error("%s: kl needs upstream, mu_w and positive prior sigmas", who);
         return BNN_E_NULL;
@@ -1203,6 +1205,7 @@ int bnn_linear_backward_input(const void *gy, int64_t gy_sample_stride, int64_t 
                               int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream)
 {
     const char *who = "bnn_linear_backward_input";
+    if (M == 0 && N >= 1 && K >= 1 && nsamples >= 1) return BNN_OK;     // empty batch
     if (!gy || !w || !gx) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldgy < N || ldgx < K) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
     const int64_t threads = (int64_t)nsamples * M * ((K + 3) / 4);
@@ -1237,6 +1240,11 @@ int bnn_colsum(const void *gy, int64_t gy_sample_stride, int64_t ldgy, float *ou
                int nsamples, int flags, void *stream)
 {
     const char *who = "bnn_colsum";
+    if (M == 0 && out && N >= 1 && nsamples >= 1) {                  // empty batch: sums are zero
+        const int rc0 = (int)hipMemsetAsync(out, 0, (size_t)nsamples * N * 4, (hipStream_t)stream);
+        if (rc0) { set_error("%s: hipMemsetAsync failed (%d)", who, rc0); return rc0; }
+        return BNN_OK;
+    }
     if (!gy || !out) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (M < 0 || N < 1 || nsamples < 1 || ldgy < N) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
     if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || nsamples > 65535) { set_error("%s: extent too large", who); return BNN_E_RANGE; }

@@ -319,7 +319,7 @@ class _SampledLinear(torch.autograd.Function):
                 g_rho_b = torch.empty_like(rho_b)
                 rb = _rng_struct(ctx.key_b, dev)
             # ... and so does the KL gradient, when KLDivergence's backward parked it for this layer
-            ent_w = _kl_take(mu_w)
+            ent_w = _kl_take(mu_w) if M > 0 else None                     # (an empty batch zero-fills; the flush adds KL)
             ent_b = _kl_take(mu_b) if (ent_w is not None and need_b and mu_b is not None) else None
             kl = _kl_fuse_struct(ent_w, ent_b) if ent_w is not None else None
             check(lib.bnn_linear_backward_weight_sampled(ptr(x), 0 if ctx.shared_x else M * K, K, ptr(gy), M * N, N,

@@ -967,6 +967,29 @@ def test_training_loop_learns_a_separable_task(env, mode):
         env["bnn"].set_compute("f32")
 
 
+def test_empty_batch_and_single_row_edges(env):
+    """Empty batch (M = 0): nothing is launched for the contraction, outputs are empty, parameter gradients are
+    exact zeros.  One row, one column, K = 4 (the smallest aligned layer): fused path == oracle."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    dev, orc = env["dev"], env["orc"]
+    mu = torch.randn(8, 12).to(dev).requires_grad_(True)
+    rho = (torch.randn(8, 12) * 0.1 - 2).to(dev).requires_grad_(True)
+    key = DrawKey(3, 9, 0, 2, 1)
+    x0 = torch.zeros(2, 0, 12, device=dev, requires_grad=True)
+    y0 = env["ops"].linear_sampled(x0, mu, rho, None, None, key, None, False)
+    assert y0.shape == (2, 0, 8)
+    gx, gm, gr = torch.autograd.grad(y0, (x0, mu, rho), torch.zeros_like(y0))
+    assert gx.shape == x0.shape and float(gm.abs().max()) == 0.0 and float(gr.abs().max()) == 0.0
+    for (Nn, K) in ((1, 4), (1, 8), (3, 4)):
+        m1 = torch.randn(Nn, K) * 0.1
+        r1 = torch.randn(Nn, K) * 0.1 - 2
+        k1 = DrawKey(4, 2, 5, 1, 0)
+        xx = torch.randn(1, 1, K)
+        got = env["ops"].linear_sampled(xx.to(dev), m1.to(dev), r1.to(dev), None, None, k1, None, False)
+        w = orc.sample_affine(m1.numpy(), r1.numpy(), orc.eps_fill(k1.seed, k1.stream, 5, k1.epoch_host, 0, (Nn, K)))
+        assert allclose(N(got)[0], orc.linear(xx[0].numpy(), w))
+
+
 # ------------------------------------------------------------------ properties at full size
 def test_full_size_linearity_property(env):
     """BASELINE size (512 x 1200 x 1200): with the draw frozen (sample=False) and no bias the
