@@ -15,6 +15,7 @@ F32, BF16 = 0, 1
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
 FLAG_RELU = 1
 FLAG_X_BF16 = 2
+E_ALIGN, E_UNSUPPORTED = -4, -6          # BNN_E_ALIGN, BNN_E_UNSUPPORTED (include/bnn_hip.h)
 FLAG_Y_BF16 = 4
 
 
@@ -93,6 +94,8 @@ SIGNATURES = {
     "bnn_linear_backward_input": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p]),
     "bnn_linear_backward_weight_sampled": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64,
                                                   _i64, _int, _rngp, _rngp, ctypes.POINTER(KlFuse), _int, _int, _int, _p]),
+    "bnn_linear_backward_narrow_sampled": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p,
+                                                  _i64, _i64, _i64, _int, _rngp, _rngp, ctypes.POINTER(KlFuse), _int, _int, _p]),
     "bnn_linear_backward_weight": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _int,
                                           _int, _int, _p]),
     "bnn_colsum": (_int, [_p, _i64, _i64, _p, _i64, _i64, _int, _int, _p]),

@@ -858,6 +858,183 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     g_rho[e] = gr;
 }
 
+// ------------------------------------------------------------------ backward of a narrow layer (N <= 16)
+// The classifier head (N = 10): 0.4 % of the FLOPs, but as tiles for the kernels above it cost 65 us of launches
+// (weight gradient + reduce, K1 draw + plain input gradient, column sums).  Here ONE pass over the activations
+// does all of it: a workgroup owns 64 columns k and 128 rows of one MC sample, a thread 4 consecutive k and
+// 1/16 of the rows; the workgroup's N x 64 weights are drawn once (the forward's bits), then per row it reads x
+// once, accumulates dW[n][k..k+3] += gy[m][n] x[m][k..k+3] and writes gx[m][k..k+3] = sum_n gy[m][n] W_s[n][k..].
+// gy of the sample (M x N fp32, 20 KB at the BASELINE shape) is staged in LDS once.  Per-sample partials
+// (dW_s, dW_s * eps_s) go to the workspace slabs that k_wgrad_reduce sums in a fixed order (and where the
+// sigmoid(rho) factor and the fused KL gradient are applied); the column sums of gy ride along for the bias.
+struct HeadBwdParams {
+    const void *x; int64_t x_sample_stride, ldx;
+    const float *gy; int64_t gy_sample_stride, ldgy;
+    const float *mu, *rho;
+    void *gx; int64_t gx_sample_stride, ldgx;      // NULL: no input gradient
+    float *slabs; int64_t slab_stride;             // [s][2][N][K]
+    float *colsums;                                // [s][N] or NULL
+    int32_t M, N, K, S;
+    RngDev rng;
+};
+
+constexpr int H_NMAX = 16, H_ROWS = 128;                         // rows per workgroup (gridDim.z row slices per sample)
+
+template <bool XBF, bool GXBF>
+__global__ __launch_bounds__(256) void k_head_bwd(const HeadBwdParams p)
+{
+    // gy rows of this workgroup's slice ([m][n], pitch N) during the row loop; the 16 x 16 partial tiles after it
+    __shared__ float smem[16 * 16 * (H_NMAX * 4 + 1)];
+    static_assert(H_ROWS * H_NMAX <= 16 * 16 * (H_NMAX * 4 + 1), "gy slice must fit the partial buffer");
+    float *gys = smem;
+    float (*part)[16][H_NMAX * 4 + 1] = reinterpret_cast<float (*)[16][H_NMAX * 4 + 1]>(smem);
+    const int tid = threadIdx.x, kg = tid & 15, mp = tid >> 4;
+    const int s = blockIdx.y, N = p.N;
+    const int k = blockIdx.x * 64 + 4 * kg;
+    const bool kok = k < p.K;                                      // K % 4 == 0: a group is in or out as a whole
+    const uint32_t edev = rng_epoch_dev(p.rng);
+    const uint32_t sample = p.rng.sample0 + (uint32_t)s;
+    const int m_lo = blockIdx.z * H_ROWS;
+    const int rows = p.M - m_lo < H_ROWS ? p.M - m_lo : H_ROWS;    // >= 1 by the grid
+
+    // stage this slice's gy rows (coalesced), and draw the thread's 4 x N weights meanwhile
+    const float *gyb = p.gy + (int64_t)s * p.gy_sample_stride + (int64_t)m_lo * p.ldgy;
+    for (int i = tid; i < rows * H_NMAX; i += 256) {                // pitch 16, columns >= N zero: the row loop needs no bounds
+        const int r = i >> 4, n = i & 15;
+        gys[i] = n < N ? gyb[(int64_t)r * p.ldgy + n] : 0.f;
+    }
+    // the workgroup's N x 64 weights are drawn ONCE (thread t < 16 N: row t / 16, column group t % 16 -- one
+    // Philox block each) and shared through LDS; every thread then keeps its column group's N x 4 in registers
+    __shared__ float4 wl[H_NMAX][16], zl[H_NMAX][16];
+    {                                                              // 256 threads = 16 rows x 16 column groups; rows >= N stay zero
+        const int n = tid >> 4, kk = blockIdx.x * 64 + 4 * (tid & 15);
+        float4 zz = make_float4(0.f, 0.f, 0.f, 0.f), ww = zz;
+        if (n < N && kk < p.K) {
+            const int64_t e0 = (int64_t)n * p.K + kk;
+            const float4 m4 = *reinterpret_cast<const float4 *>(p.mu + e0), r4 = *reinterpret_cast<const float4 *>(p.rho + e0);
+            zz = eps4(p.rng, edev, (uint32_t)(e0 >> 2), sample);
+            ww = make_float4(fmaf(sigma_draw(r4.x), zz.x, m4.x), fmaf(sigma_draw(r4.y), zz.y, m4.y),
+                             fmaf(sigma_draw(r4.z), zz.z, m4.z), fmaf(sigma_draw(r4.w), zz.w, m4.w));
+        }
+        wl[n][tid & 15] = ww;
+        zl[n][tid & 15] = zz;
+    }
+    float cs[H_NMAX];
+#pragma unroll
+    for (int n = 0; n < H_NMAX; ++n) cs[n] = 0.f;
+    __syncthreads();
+    float4 w[H_NMAX], dW[H_NMAX];                                  // (eps stays in LDS until the epilogue: 2 x 64 VGPRs, not 3 x)
+#pragma unroll
+    for (int n = 0; n < H_NMAX; ++n) {
+        dW[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w[n] = wl[n][kg];
+    }
+
+    auto load_x = [&](int r) -> float4 {
+        const int64_t xo = (int64_t)s * p.x_sample_stride + (int64_t)(m_lo + r) * p.ldx + k;
+        if constexpr (XBF) {
+            const uint2 h = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p.x) + xo);
+            return make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xFFFF0000u),
+                               __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xFFFF0000u));
+        } else {
+            return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.x) + xo);
+        }
+    };
+    // rows mp, mp + 16, ...: four at a time, their x loads in flight together (the loop is latency-bound otherwise)
+    for (int r0 = mp; r0 < rows; r0 += 64) {
+        float4 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 16 * u;
+            xv[u] = (kok && r < rows) ? load_x(r) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 16 * u;
+            if (r < rows) {
+            float g[H_NMAX];
+#pragma unroll
+            for (int q4 = 0; q4 < H_NMAX / 4; ++q4) {
+                const float4 t = *reinterpret_cast<const float4 *>(gys + r * H_NMAX + 4 * q4);
+                g[4 * q4] = t.x; g[4 * q4 + 1] = t.y; g[4 * q4 + 2] = t.z; g[4 * q4 + 3] = t.w;
+            }
+            if (kg == 0 && blockIdx.x == 0) {
+#pragma unroll
+                for (int n = 0; n < H_NMAX; ++n) cs[n] += g[n];
+            }
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < H_NMAX; ++n) {                     // columns >= N carry g = 0, w = 0: straight-line code
+                dW[n].x = fmaf(g[n], xv[u].x, dW[n].x); dW[n].y = fmaf(g[n], xv[u].y, dW[n].y);
+                dW[n].z = fmaf(g[n], xv[u].z, dW[n].z); dW[n].w = fmaf(g[n], xv[u].w, dW[n].w);
+                o.x = fmaf(g[n], w[n].x, o.x); o.y = fmaf(g[n], w[n].y, o.y);
+                o.z = fmaf(g[n], w[n].z, o.z); o.w = fmaf(g[n], w[n].w, o.w);
+            }
+            if (kok && p.gx) {
+                const int64_t go = (int64_t)s * p.gx_sample_stride + (int64_t)(m_lo + r) * p.ldgx + k;
+                if constexpr (GXBF) {
+                    uint2 h;
+                    h.x = pack_bf16x2(o.x, o.y);
+                    h.y = pack_bf16x2(o.z, o.w);
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(p.gx) + go) = h;
+                } else {
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.gx) + go) = o;
+                }
+            }
+            }
+        }
+    }
+    __syncthreads();                                               // gys is dead: its storage becomes the partial tiles
+    // fixed-order reduction of the 16 row slices, then (dW, dW * eps) of this (sample, row slice) to its slab
+#pragma unroll
+    for (int n = 0; n < H_NMAX; ++n) {
+        part[mp][kg][n * 4 + 0] = dW[n].x; part[mp][kg][n * 4 + 1] = dW[n].y;
+        part[mp][kg][n * 4 + 2] = dW[n].z; part[mp][kg][n * 4 + 3] = dW[n].w;
+    }
+    __syncthreads();
+    const int slab = s * gridDim.z + blockIdx.z;
+    {
+        // all 256 threads: output o = (n, c) with c = 4 kg + j the column inside the 64-wide slice (fastest: the
+        // stores of a row n are 256 contiguous bytes); 16 independent LDS reads each, added in a fixed order
+        float *sm = p.slabs + (int64_t)slab * p.slab_stride, *sr = sm + (int64_t)N * p.K;
+        for (int o = tid; o < N * 64; o += 256) {
+            const int n = o >> 6, c = o & 63;
+            const int kk = blockIdx.x * 64 + c;
+            if (kk >= p.K) continue;
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += part[q][c >> 2][n * 4 + (c & 3)];
+            const float4 zz = zl[n][c >> 2];
+            const float ze = (c & 3) == 0 ? zz.x : (c & 3) == 1 ? zz.y : (c & 3) == 2 ? zz.z : zz.w;
+            sm[(int64_t)n * p.K + kk] = t;
+            sr[(int64_t)n * p.K + kk] = t * ze;
+        }
+    }
+    if (p.colsums && blockIdx.x == 0) {                            // column sums of gy (bias): the kg == 0 threads hold them
+        __syncthreads();
+        if (kg == 0)
+#pragma unroll
+            for (int n = 0; n < H_NMAX; ++n) part[mp][0][n] = cs[n];
+        __syncthreads();
+        if (tid < N) {
+            float t = 0.f;
+            for (int q = 0; q < 16; ++q) t += part[q][0][tid];
+            p.colsums[(int64_t)slab * N + tid] = t;                // per (sample, row slice); summed over slices below
+        }
+    }
+}
+
+// colsums[(s, z)][n] -> out[s][n]: fixed-order sum over the row slices
+__global__ void k_head_colsum_fold(const float *__restrict__ cs, float *__restrict__ out, int S, int Z, int N)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * N) return;
+    const int s = i / N, n = i % N;
+    float t = 0.f;
+    for (int zz = 0; zz < Z; ++zz) t += cs[((int64_t)s * Z + zz) * N + n];
+    out[i] = t;
+}
+
 // ------------------------------------------------------------------ input gradient, explicit weights
 // gx[s][m][k0..k0+3] = sum_n gy[s][m][n] * w[s][n][k0..k0+3]; one thread per (s, m, 4 columns).  For
 // layers with few outputs (the 10-wide head) or shapes the fused kernel does not take.
@@ -1157,6 +1334,67 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
                        p.nsplit, rho_w, g_mu, g_rho, n, accumulate, kl ? kl->upstream : nullptr, kl ? kl->mu_w : nullptr,
                        kl ? kl->scale_w : 0.f, kl ? kl->prior_mu_w : 0.f, kl ? kl->prior_sigma_w : 1.f);
     return check_launch(who);
+}
+
+int bnn_linear_backward_narrow_sampled(const void *x, int64_t x_sample_stride, int64_t ldx, const float *gy,
+                                       int64_t gy_sample_stride, int64_t ldgy, const float *mu_w, const float *rho_w,
+                                       void *gx, int64_t gx_sample_stride, int64_t ldgx, float *g_mu, float *g_rho,
+                                       const float *rho_b, float *g_mu_b, float *g_rho_b, int64_t M, int64_t N, int64_t K,
+                                       int nsamples, const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
+                                       const bnn_kl_fuse_t *kl, int flags, int accumulate, void *stream)
+{
+    const char *who = "bnn_linear_backward_narrow_sampled";
+    if (!x || !gy || !mu_w || !rho_w || !g_mu || !g_rho) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    const bool want_bias = rho_b || g_mu_b || g_rho_b;
+    if (want_bias && (!rho_b || !g_mu_b || !g_rho_b || !rng_b)) { set_error("%s: rho_b, g_mu_b, g_rho_b, rng_b must be given together", who); return BNN_E_NULL; }
+    if (kl && (!kl->upstream || !kl->mu_w || !(kl->prior_sigma_w > 0.f) || (kl->mu_b && !(kl->prior_sigma_b > 0.f)))) { set_error("%s: kl needs upstream, mu_w and positive prior sigmas", who); return BNN_E_NULL; }
+    if (M < 1 || N < 1 || N > H_NMAX || K < 4 || K % 4 != 0 || nsamples < 1 || nsamples > 65535 || ldx < K || ldgy < N || (gx && ldgx < K)) { set_error("%s: needs 1 <= N <= 16, K %% 4 == 0, M >= 1", who); return BNN_E_UNSUPPORTED; }
+    const bool xh = (flags & BNN_FLAG_X_BF16) != 0, gxh = (flags & BNN_FLAG_Y_BF16) != 0;
+    const int xe = xh ? 2 : 4, ge = gxh ? 2 : 4;
+    if (!al16(mu_w) || !al16(rho_w) || !al16(g_mu) || !al16(g_rho) || (reinterpret_cast<uintptr_t>(x) & (4 * xe - 1)) || (ldx * xe) % (4 * xe) != 0 ||
+        (x_sample_stride * xe) % (4 * xe) != 0 || (gx && ((reinterpret_cast<uintptr_t>(gx) & (4 * ge - 1)) || (gx_sample_stride * ge) % (4 * ge) != 0))) {
+        set_error("%s: misaligned operand", who);
+        return BNN_E_ALIGN;
+    }
+    int rc = check_rng(rng_w, nsamples);
+    if (rc) { set_error("%s: bad rng_w", who); return rc; }
+    GemmParams ws{};
+    fill_workspace(ws);
+    const int64_t Z = (M + H_ROWS - 1) / H_ROWS, nslab = (int64_t)nsamples * Z;
+    const int64_t need = (nslab * 2 * N * K + nslab * N + (int64_t)nsamples * N) * 4;
+    if (!ws.ws_slabs || need > ws.ws_slab_bytes || Z > 65535 || nslab > 0x7FFFFFFF) { set_error("%s: registered workspace too small (%lld bytes needed)", who, (long long)need); return BNN_E_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    HeadBwdParams p{};
+    p.x = x; p.x_sample_stride = x_sample_stride; p.ldx = ldx;
+    p.gy = gy; p.gy_sample_stride = gy_sample_stride; p.ldgy = ldgy;
+    p.mu = mu_w; p.rho = rho_w; p.gx = gx; p.gx_sample_stride = gx_sample_stride; p.ldgx = ldgx;
+    p.slabs = ws.ws_slabs; p.slab_stride = 2 * N * K;
+    float *cs_parts = ws.ws_slabs + nslab * p.slab_stride, *cs_sum = cs_parts + nslab * N;
+    p.colsums = want_bias ? cs_parts : nullptr;
+    p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.rng = make_rng(rng_w);
+    const dim3 grid((unsigned)((K + 63) / 64), (unsigned)nsamples, (unsigned)Z);
+    if (xh && gxh) hipLaunchKernelGGL((k_head_bwd<true, true>), grid, dim3(256), 0, st, p);
+    else if (xh) hipLaunchKernelGGL((k_head_bwd<true, false>), grid, dim3(256), 0, st, p);
+    else if (gxh) hipLaunchKernelGGL((k_head_bwd<false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_head_bwd<false, false>), grid, dim3(256), 0, st, p);
+    rc = check_launch(who);
+    if (rc) return rc;
+    const int64_t n = N * K;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws.ws_slabs, p.slab_stride, (int)nslab,
+                       rho_w, g_mu, g_rho, n, accumulate, kl ? kl->upstream : nullptr, kl ? kl->mu_w : nullptr,
+                       kl ? kl->scale_w : 0.f, kl ? kl->prior_mu_w : 0.f, kl ? kl->prior_sigma_w : 1.f);
+    rc = check_launch(who);
+    if (rc || !want_bias) return rc;
+    hipLaunchKernelGGL(k_head_colsum_fold, dim3((unsigned)((nsamples * N + 255) / 256)), dim3(256), 0, st, cs_parts, cs_sum, nsamples, (int)Z, (int)N);
+    rc = check_launch(who);
+    if (rc) return rc;
+    rc = bnn_sample_affine_bwd(cs_sum, N, rho_b, nullptr, 0, rng_b, N, nsamples, g_mu_b, g_rho_b, accumulate, stream);
+    if (!rc && kl && kl->mu_b) {
+        const bnn_kl_tensor_t kt = {kl->mu_b, rho_b, N, kl->prior_mu_b, kl->prior_sigma_b};
+        float *gmp[1] = {g_mu_b}, *grp[1] = {g_rho_b};
+        rc = bnn_kl_backward(&kt, 1, 1.0f / (kl->scale_b * (float)N), kl->upstream, gmp, grp, 1, stream);
+    }
+    return rc;
 }
 
 int bnn_linear_backward_weight(const void *x, int64_t x_sample_stride, int64_t ldx, const void *gy,

@@ -292,6 +292,35 @@ class _SampledLinear(torch.autograd.Function):
         gflag = _lib.FLAG_X_BF16 if _bf(gy) else 0
         rw = _rng_struct(ctx.key_w, dev)
         gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if N <= 16 and K % 4 == 0 and M > 0 and need_w and not _bf(gy) and not (ctx.shared_x and ctx.needs_input_grad[0]):
+            # narrow layer (classifier head): the whole backward in one pass over the activations
+            need_b = rho_b is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+            g_mu_w, g_rho_w = torch.empty_like(mu_w), torch.empty_like(rho_w)
+            rb = None
+            if need_b:
+                g_mu_b, g_rho_b = torch.empty_like(rho_b), torch.empty_like(rho_b)
+                rb = _rng_struct(ctx.key_b, dev)
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty((S, M, K), dtype=x.dtype, device=dev)
+            ent_w = _kl_take(mu_w)
+            ent_b = _kl_take(mu_b) if (ent_w is not None and need_b and mu_b is not None) else None
+            kl = _kl_fuse_struct(ent_w, ent_b) if ent_w is not None else None
+            flags = (_lib.FLAG_X_BF16 if _bf(x) else 0) | (_lib.FLAG_Y_BF16 if (gx is not None and _bf(gx)) else 0)
+            rc = lib.bnn_linear_backward_narrow_sampled(
+                ptr(x), 0 if ctx.shared_x else M * K, K, ptr(gy), M * N, N, ptr(mu_w), ptr(rho_w), ptr(gx), M * K, K,
+                ptr(g_mu_w), ptr(g_rho_w), ptr(rho_b) if need_b else None, ptr(g_mu_b), ptr(g_rho_b), M, N, K, S,
+                ctypes.byref(rw), ctypes.byref(rb) if rb is not None else None,
+                ctypes.byref(kl) if kl is not None else None, flags, 0, stream_ptr(dev))
+            if rc == 0:
+                return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None
+            if rc not in (_lib.E_UNSUPPORTED, _lib.E_ALIGN):
+                check(rc, "bnn_linear_backward_narrow_sampled")
+            # not applicable here (workspace, alignment): the general kernels below; hand the KL entries back
+            for e in (ent_w, ent_b):
+                if e is not None:
+                    _kl_pending[(e.mu.device.index, e.mu.data_ptr())] = e
+            gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
         if ctx.needs_input_grad[0]:
             # a shared input sums its gradient over the samples: fp32 partials, then one reduction
             gx_dtype = torch.float32 if ctx.shared_x else x.dtype

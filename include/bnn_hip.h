@@ -233,6 +233,20 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
                                        const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
                                        const bnn_kl_fuse_t *kl,
                                        int compute, int flags, int accumulate, void *stream);
+/* Whole backward of a NARROW layer (N <= 16, K % 4 == 0: a classifier head) in one pass over the
+ * activations: gx (may be NULL), g_mu / g_rho of the weight, and the bias gradients -- same definitions
+ * as the three entry points above.  gy fp32; flags: BNN_FLAG_X_BF16 = x is bf16, BNN_FLAG_Y_BF16 = gx
+ * is written as bf16.  Needs the registered workspace (S * (2 N K + N) floats); BNN_E_UNSUPPORTED
+ * otherwise (callers then use the general entry points). */
+int bnn_linear_backward_narrow_sampled(const void *x, int64_t x_sample_stride, int64_t ldx,
+                                       const float *gy, int64_t gy_sample_stride, int64_t ldgy,
+                                       const float *mu_w, const float *rho_w,
+                                       void *gx, int64_t gx_sample_stride, int64_t ldgx,
+                                       float *g_mu, float *g_rho,
+                                       const float *rho_b, float *g_mu_b, float *g_rho_b,
+                                       int64_t M, int64_t N, int64_t K, int nsamples,
+                                       const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
+                                       const bnn_kl_fuse_t *kl, int flags, int accumulate, void *stream);
 /* F.linear's own weight gradient, per sample: gw[s][n][k] (+)= sum_m gy[s][m][n] * x[s][m][k],
  * gw[s] = gw + s * gw_sample_stride (parity mode, where the draw is a separate op). */
 int bnn_linear_backward_weight(const void *x, int64_t x_sample_stride, int64_t ldx,

@@ -704,10 +704,14 @@ def test_backward_kernels_bf16_mode(env, S, M, Nn, K):
         gx, g_mu, g_rho = torch.autograd.grad(y, (xd, mud, rhod), gy.to(dev).to(act_dtype))
         want_mu, want_rho, want_x = _oracle_linear_bwd(orc, mu, rho, x, gy, eps, False, rounder=orc.bf16_round)
         exact_mu, exact_rho, exact_x = _oracle_linear_bwd(orc, mu, rho, x, gy, eps, False)
-        assert allclose_scaled(N(g_mu), want_mu, 2e-3)
-        assert allclose_scaled(N(g_rho), want_rho, 2e-3)
-        assert allclose_scaled(N(gx.float()), want_x, 2e-3 if act_dtype == torch.float32 else 1e-2)
-        assert allclose_scaled(N(g_mu), exact_mu, 2e-2) and allclose_scaled(N(gx.float()), exact_x, 2e-2)
+        if Nn > 16:
+            assert allclose_scaled(N(g_mu), want_mu, 2e-3)
+            assert allclose_scaled(N(g_rho), want_rho, 2e-3)
+            assert allclose_scaled(N(gx.float()), want_x, 2e-3 if act_dtype == torch.float32 else 1e-2)
+        # (N <= 16 runs the narrow-layer kernel, which keeps fp32 operands: closer to the exact gradient
+        # than to the bf16-rounded restatement)
+        assert allclose_scaled(N(g_mu), exact_mu, 2e-2) and allclose_scaled(N(g_rho), exact_rho, 2e-2)
+        assert allclose_scaled(N(gx.float()), exact_x, 2e-2)
 
 
 @pytest.mark.parametrize("mode,M", [("f32", 70), ("bf16", 256), ("bf16", 72)])
