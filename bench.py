@@ -349,6 +349,32 @@ def sampler_roofline(dev, iters=20):
             "avg_launch_us": round(ms * 1e3, 1)}
 
 
+def kl_roofline(dev, iters=20):
+    """K3 alone on a working set beyond the Infinity Cache (64 Mi posterior scalars = 512 MiB read):
+    HBM-bound, 8 algorithmic bytes per scalar (mu, rho), one double partial per 2048 scalars written."""
+    from bayesianneuralnetworks_amd import ops
+    n = 64 << 20
+    mu = torch.zeros(n, device=dev)
+    rho = torch.full((n,), -2.0, device=dev)
+    out = torch.empty(2, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            ops.kl_normal([mu], [rho], [(0.0, 0.1)], 1.0, out=out)
+        torch.cuda.synchronize(dev)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.kl_normal([mu], [rho], [(0.0, 0.1)], 1.0, out=out)
+        e1.record()
+        torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    gbs = 8.0 * n / (ms * 1e-3) / 1e9
+    return {"kernel": "k_kl_partial + k_kl_final, 64Mi scalars", "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            "avg_launch_us": round(ms * 1e3, 1)}
+
+
 def cpu_baseline(post, x_cpu):
     """The torch-CPU port of the reference (oracle/reference_port.py, pinned bit-for-bit to the
     reference by tests/test_oracle_golden.py) on this machine's host cores."""
@@ -468,6 +494,7 @@ def main():
                            "note": "same step, exact fp32 MFMA (the 1e-5 parity mode)"}
         line["roofline"] = kernel_roofline(net, x, args.dtype, dev)
         line["roofline_sampler"] = sampler_roofline(dev)
+        line["roofline_kl"] = kl_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(post, x_cpu)
         print(json.dumps(line), flush=True)
