@@ -81,6 +81,7 @@ SIGNATURES = {
     "bnn_sigma": (_int, [_p, _p, _i64, _p]),
     "bnn_sample_affine_bwd": (_int, [_p, _i64, _p, _p, _i64, _rngp, _i64, _int, _p, _p, _int, _p]),
     "bnn_rng_advance": (_int, [_p, ctypes.c_uint32, _p]),
+    "bnn_prune_score": (_int, [_p, _p, _p, _i64, _p]),
     "bnn_kl_workspace_bytes": (_i64, [_int]),
     "bnn_kl_forward": (_int, [ctypes.POINTER(KlTensor), _int, _f, _p, _p, _p]),
     "bnn_kl_backward": (_int, [ctypes.POINTER(KlTensor), _int, _f, _p, ctypes.POINTER(_p),

@@ -196,6 +196,19 @@ __global__ __launch_bounds__(kThreads) void k_sample_affine_bwd(
     }
 }
 
+// PruneNormal's score (prune/prune.py:11): log N(0; mu, sigma(rho)) = -mu^2 / (2 sigma^2) - ln sigma - ln sqrt(2 pi)
+__global__ __launch_bounds__(kThreads) void k_prune_score(const float *__restrict__ mu, const float *__restrict__ rho,
+                                                          float *__restrict__ out, int64_t n)
+{
+    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = tid; i < n; i += nthreads) {
+        const float sg = sigma_accurate(rho[i]);
+        const float t = mu[i] / sg;
+        out[i] = -0.5f * t * t - __builtin_amdgcn_logf(sg) * 0.693147180559945309f - 0.918938533204672742f;
+    }
+}
+
 __global__ void k_rng_advance(uint32_t *epoch_dev, uint32_t inc) { epoch_dev[0] += inc; }
 
 // ---------------------------------------------------------------- MC reduction
@@ -352,6 +365,15 @@ int bnn_sample_affine_bwd(const float *g_w, int64_t g_w_sample_stride, const flo
     else
         hipLaunchKernelGGL((k_sample_affine_bwd<false>), dim3(grid), dim3(kThreads), 0, st, g_w, g_w_sample_stride, rho, eps, eps_sample_stride, rd, n, nsamples, g_mu, g_rho, accumulate);
     return check_launch("bnn_sample_affine_bwd");
+}
+
+int bnn_prune_score(const float *mu, const float *rho, float *out, int64_t n, void *stream)
+{
+    if (!mu || !rho || !out) { set_error("bnn_prune_score: NULL pointer"); return BNN_E_NULL; }
+    if (n < 0) { set_error("bnn_prune_score: n < 0"); return BNN_E_SHAPE; }
+    if (n == 0) return BNN_OK;
+    hipLaunchKernelGGL(k_prune_score, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, mu, rho, out, n);
+    return check_launch("bnn_prune_score");
 }
 
 int bnn_rng_advance(uint32_t *epoch_dev, uint32_t inc, void *stream)

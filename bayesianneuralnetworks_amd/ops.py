@@ -765,3 +765,14 @@ class _SoftmaxXent(torch.autograd.Function):
 def cross_entropy(logits, target):
     """Mean cross-entropy of (rows, classes) fp32 logits against int64 class indices."""
     return _SoftmaxXent.apply(logits.contiguous(), target.contiguous())
+
+
+def prune_score(mu, rho):
+    """log N(0; mu, sigma(rho)) element-wise (PruneNormal's ranking score, prune/prune.py:11)."""
+    require_cuda_f32(mu, "mean")
+    require_cuda_f32(rho, "scale")
+    mu_c, rho_c = mu.detach().contiguous(), rho.detach().contiguous()
+    out = torch.empty_like(mu_c)
+    check(_lib.load().bnn_prune_score(ptr(mu_c), ptr(rho_c), ptr(out), mu_c.numel(), stream_ptr(mu_c.device)),
+          "bnn_prune_score")
+    return out

@@ -1,4 +1,5 @@
-"""Signal-to-noise pruning (pytorch_bayesian/prune/prune.py:5-22); offline, PyTorch ops."""
+"""Signal-to-noise pruning (pytorch_bayesian/prune/prune.py:5-22).  On the device the score log N(0; mu, sigma) is
+a HIP kernel (bnn_prune_score); the top-k selection and the masked assignment are torch ops on the device."""
 import torch
 
 from ..utils import apply_wb
@@ -13,8 +14,12 @@ class PruneNormal:
         """prune.py:10-17: the `percentage` entries whose posterior puts the most density on 0
         get mean = 0, scale = -30.  (log_prob is given a tensor: current torch rejects the
         reference's Python-int argument.)"""
-        zero = torch.zeros((), device=param.mean.device, dtype=param.mean.dtype)
-        log_prob = param.dist.log_prob(zero)
+        if param.mean.is_cuda:
+            from .. import ops
+            log_prob = ops.prune_score(param.mean, param.scale)
+        else:
+            zero = torch.zeros((), device=param.mean.device, dtype=param.mean.dtype)
+            log_prob = param.dist.log_prob(zero)
         flat = log_prob.flatten()
         k = int(percentage * flat.size(0))
         _, idx = torch.topk(flat, k)

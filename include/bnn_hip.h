@@ -345,6 +345,12 @@ int64_t bnn_xent_workspace_bytes(int64_t rows);
 int bnn_softmax_xent(const float *logits, const int64_t *target, int64_t rows, int classes,
                      float *loss, float *g_logits, void *workspace, void *stream);
 
+/* ---- pruning score --------------------------------------------
+ * replaces  param.dist.log_prob(0)   pytorch_bayesian/prune/prune.py:11
+ *   out[i] = log N(0; mu[i], sigma(rho[i])) = -mu^2 / (2 sigma^2) - ln sigma - ln sqrt(2 pi)
+ * (the top-k selection and the masked assignment of prune.py:12-17 stay torch ops on the device). */
+int bnn_prune_score(const float *mu, const float *rho, float *out, int64_t n, void *stream);
+
 /* ---- MC reduction ----------------------------------------------------------
  * replaces  torch.stack(preds).mean(0)   examples/MNIST/uncertainty.py:50
  *   out[i] (+)= scale * sum_s y[s * y_sample_stride + i],  i < n.

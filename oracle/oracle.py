@@ -177,6 +177,13 @@ def linear_bwd(mu, rho, x, gy, eps, shared_x=False, rounder=None):
     return g_mu, g_rho, np.stack(gx)
 
 
+def prune_score(mu, rho):
+    """PruneNormal's ranking score, prune/prune.py:11: Normal(mu, sigma).log_prob(0), sigma as in core.py:25-27 (float64)."""
+    sg = sigma(rho).astype(np.float64)
+    m = np.asarray(mu, np.float64)
+    return -0.5 * (m / sg) ** 2 - np.log(sg) - 0.5 * np.log(2.0 * np.pi)
+
+
 def kl_bwd(mu, rho, prior_mu, prior_sigma, scale):
     """orc_kl_bwd -- autograd of loss.py:28 times `scale`."""
     m, mp = _c(mu)

@@ -881,6 +881,45 @@ def test_sampled_conv2d_backward_vs_float64_autograd(env, cfg, mode):
         assert allclose_scaled(N(got), w_.numpy(), tol)
 
 
+# ------------------------------------------------------------------ pruning
+def test_prune_normal_on_device(env):
+    """prune/prune.py:7-22 on the device: HIP score == oracle; half of every tensor pruned to (0, -30); the
+    pruned model still runs and its state_dict round-trips (examples/MNIST/prune.py:47-58)."""
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule, KLDivergence
+    from bayesianneuralnetworks_amd.prune import PruneNormal
+    dev, orc = env["dev"], env["orc"]
+    gen = torch.Generator().manual_seed(12)
+    mu = torch.randn(257, 33, generator=gen) * 0.3
+    rho = torch.randn(257, 33, generator=gen) * 2 - 2
+    rho[0, :4] = torch.tensor([-30.0, 25.0, 19.9, 0.0])
+    got = N(env["ops"].prune_score(mu.to(dev), rho.to(dev)))
+    want = orc.prune_score(mu.numpy(), rho.numpy())
+    assert np.allclose(got, want, rtol=2e-5, atol=2e-5)
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(12, 5, 2)
+            self.layers = torch.nn.Sequential(NormalLinear(12, 40), torch.nn.ReLU(), NormalLinear(40, 5))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    net = Net().to(dev)
+    n0 = env["lib"].bnn_launch_count()
+    PruneNormal()(net, 0.5)
+    assert env["lib"].bnn_launch_count() >= n0 + 4           # one score launch per posterior tensor
+    for L in (net.layers[0], net.layers[2]):
+        frac = (L.weight.scale == -30).float().mean().item()
+        assert abs(frac - 0.5) < 0.02
+        assert bool(((L.weight.scale == -30) == (L.weight.mean == 0)).all())
+    y = net(torch.randn(7, 12, device=dev))
+    assert len(y) == 2 and torch.isfinite(y[0]).all()
+    assert torch.isfinite(KLDivergence()(net))
+    net2 = Net().to(dev)
+    net2.load_state_dict(net.state_dict())
+    assert torch.equal(net2.layers[0].weight.scale, net.layers[0].weight.scale)
+
+
 # ------------------------------------------------------------------ training-loop callers
 def test_fused_adam_matches_torch_adam(env):
     """optim.Adam (one HIP launch for all tensors) against torch.optim.Adam (train.py:41,65) over 6 steps,

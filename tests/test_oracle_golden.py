@@ -208,3 +208,11 @@ def test_oracle_linear_bwd_matches_reference_autograd(name):
     assert np.allclose(g_mu + km, g["g_mu_w"], rtol=1e-4, atol=1e-5)
     assert np.allclose(g_rho + kr, g["g_rho_w"], rtol=1e-4, atol=1e-5)
     assert np.allclose(gx[0], g["g_x"], rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_prune_score_is_the_reference_log_prob():
+    """prune/prune.py:11 with a tensor argument (the reference's int argument fails on current torch)."""
+    g = load_golden("linear_64x48")
+    mu, rho = torch.from_numpy(g["mu_w"]), torch.from_numpy(g["rho_w"])
+    want = torch.distributions.Normal(mu, 1e-10 + torch.nn.functional.softplus(rho)).log_prob(torch.zeros(()))
+    assert np.allclose(orc.prune_score(g["mu_w"], g["rho_w"]), want.numpy(), rtol=1e-5, atol=1e-5)
