@@ -606,6 +606,35 @@ class _PlainConv2d(torch.autograd.Function):
         S = w.shape[0]
         gy = gy.contiguous()
         gx = gw = gb = None
+        sh, OH, OW = _conv_shape(x.shape[-4:], w.shape[1:], stride, padding, dilation, groups)
+        K = w[0, 0].numel()
+        if groups == 1 and K % 8 == 0:
+            # all-HIP backward through the im2col panel (exact fp32 here: parity mode / Flipout): the conv is
+            # F.linear on rows = (image, pixel), see include/bnn_hip.h 'backward of K2 conv2d'
+            lib, dev, st = _lib.load(), gy.device, stream_ptr(gy.device)
+            _lib.ensure_workspace(dev)
+            P, O = OH * OW, sh.O
+            M = sh.B * P
+            rows = torch.empty((S, M, O), dtype=torch.float32, device=dev)
+            check(lib.bnn_nchw_to_rows(ptr(gy), S * sh.B, O, P, ptr(rows), 0, st), "bnn_nchw_to_rows")
+            if ctx.needs_input_grad[1]:
+                nsx = 1 if ctx.shared_x else S
+                panel = torch.empty((nsx, M, K), dtype=torch.float32, device=dev)
+                per = sh.B * sh.C * sh.H * sh.W
+                check(lib.bnn_conv2d_im2col(ptr(x), 0 if ctx.shared_x else per, ctypes.byref(sh), nsx, ptr(panel), 0, st),
+                      "bnn_conv2d_im2col")
+                gw = torch.empty_like(w)
+                check(lib.bnn_linear_backward_weight(ptr(panel), 0 if ctx.shared_x else M * K, K, ptr(rows), M * O, O,
+                                                     ptr(gw), O * K, M, O, K, S, _lib.COMPUTE_F32, 0, 0, st),
+                      "bnn_linear_backward_weight")
+            if ctx.needs_input_grad[0]:
+                gpanel = _dgrad_plain_raw(rows, w.reshape(S, O, K), torch.float32)          # (S, M, K)
+                gx = torch.empty((sh.B, sh.C, sh.H, sh.W) if ctx.shared_x else (S, sh.B, sh.C, sh.H, sh.W),
+                                 dtype=torch.float32, device=dev)
+                check(lib.bnn_conv2d_col2im(ptr(gpanel), ctypes.byref(sh), S, int(ctx.shared_x), ptr(gx), st), "bnn_conv2d_col2im")
+            if ctx.has_b and ctx.needs_input_grad[2]:
+                gb = _colsum_raw(rows)
+            return gx, gw, gb, None, None, None
         gxs, gws = [], []
         for s in range(S):
             xs_ = x if ctx.shared_x else x[s]

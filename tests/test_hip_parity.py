@@ -881,6 +881,30 @@ def test_sampled_conv2d_backward_vs_float64_autograd(env, cfg, mode):
         assert allclose_scaled(N(got), w_.numpy(), tol)
 
 
+@pytest.mark.parametrize("shared", [False, True])
+def test_plain_conv2d_backward_panel_vs_float64_autograd(env, shared):
+    """Explicit-weight conv2d (parity mode, Flipout): backward through the panel -- rows, im2col, per-sample
+    weight gradient, plain input gradient, col2im, column sums -- against float64 autograd of F.conv2d."""
+    dev = env["dev"]
+    gen = torch.Generator().manual_seed(23)
+    S, B, C, H, W, O, k, st, pd = 2, 3, 8, 7, 6, 12, 3, 2, 1
+    w = torch.randn(S, O, C, k, k, generator=gen) * 0.2
+    b = torch.randn(S, O, generator=gen) * 0.1
+    x = torch.randn((B, C, H, W) if shared else (S, B, C, H, W), generator=gen)
+    xd, wd, bd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    n0 = env["lib"].bnn_launch_count()
+    y = env["ops"].conv2d_plain(xd, wd, bd, shared, (st, st), (pd, pd), (1, 1), 1, "f32")
+    gy = torch.randn(y.shape, generator=gen)
+    gx, gw, gb = torch.autograd.grad(y, (xd, wd, bd), gy.to(dev))
+    assert env["lib"].bnn_launch_count() >= n0 + 6
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y64 = torch.stack([torch.nn.functional.conv2d(x64 if shared else x64[s_], w64[s_], b64[s_], st, pd) for s_ in range(S)])
+    assert allclose_scaled(N(y), y64.detach().numpy())
+    want = torch.autograd.grad(y64, (x64, w64, b64), gy.double())
+    for got, w_ in zip((gx, gw, gb), want):
+        assert got.shape == w_.shape and allclose_scaled(N(got), w_.numpy(), 2e-5)
+
+
 # ------------------------------------------------------------------ pruning (SURVEY 8f-3)
 def test_prune_normal_on_device(env):
     """prune/prune.py:7-22 on the device: HIP score == oracle; half of every tensor pruned to (0, -30); the
