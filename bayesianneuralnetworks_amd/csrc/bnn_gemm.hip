@@ -480,6 +480,20 @@ __global__ __launch_bounds__(256) void k_im2col(const float *__restrict__ x, int
     }
 }
 
+// Launch of the panel kernel (returns after the launch; the caller checks it).
+static void launch_im2col(const float *x, int64_t x_sample_stride, void *panel, const bnn_conv2d_shape_t *sh, int64_t OH, int64_t OW,
+                          int64_t K, int nsx, int64_t M, bool bf, hipStream_t st)
+{
+    const int64_t rows = (int64_t)nsx * M;
+    // (a one-workgroup-per-row form with a compile-time 3 x 3 window was measured: no gain at K = 1152, 1.6x
+    // slower at K = 576 -- too few threads per row)
+    const int64_t groups8 = rows * (K / 8);
+    int64_t blocks = (groups8 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (bf) hipLaunchKernelGGL((k_im2col<true>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, panel, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
+    else hipLaunchKernelGGL((k_im2col<false>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, panel, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
+}
+
 // Inverse of the panel for the input gradient: gx[s][b][c][ih][iw] = sum over the kernel taps (kh, kw) that
 // reach (ih, iw) of gpanel[(s, b, oh, ow)][(c, kh, kw)] -- a gather (no atomics, one thread per input
 // element, fixed summation order).  SHARED: the input was shared by all samples, so sum over s as well.
@@ -582,12 +596,8 @@ static int conv_common(const float *x, int64_t x_sample_stride, const float *w, 
         if (fast) {
             const bool bf = compute == BNN_COMPUTE_BF16;
             const int nsx = x_sample_stride == 0 ? 1 : nsamples;
-            const int64_t groups8 = (int64_t)nsx * M * (K / 8);
-            int64_t blocks = (groups8 + 255) / 256;
-            if (blocks > 65536) blocks = 65536;
             hipStream_t st = (hipStream_t)stream;
-            if (bf) hipLaunchKernelGGL((k_im2col<true>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, workspace, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
-            else hipLaunchKernelGGL((k_im2col<false>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, workspace, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
+            launch_im2col(x, x_sample_stride, workspace, sh, OH, OW, K, nsx, M, bf, st);
             int rc = check_launch(who);
             if (rc) return rc;
             GemmParams q{};
@@ -698,12 +708,7 @@ int bnn_conv2d_im2col(const float *x, int64_t x_sample_stride, const bnn_conv2d_
     if (!x || !panel) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     const int64_t K = (int64_t)sh->C * sh->KH * sh->KW, M = (int64_t)sh->B * OH * OW;
     if (K % 8 != 0 || x_samples < 1 || M > 0x7FFFFFFF || !al16(panel)) { set_error("%s: needs C*KH*KW %% 8 == 0, a 16-B aligned panel", who); return BNN_E_UNSUPPORTED; }
-    const int64_t groups8 = (int64_t)x_samples * M * (K / 8);
-    int64_t blocks = (groups8 + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    hipStream_t st = (hipStream_t)stream;
-    if (out_bf16) hipLaunchKernelGGL((k_im2col<true>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, panel, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
-    else hipLaunchKernelGGL((k_im2col<false>), dim3((unsigned)blocks), dim3(256), 0, st, x, x_sample_stride, panel, sh->B, sh->C, sh->H, sh->W, (int)OH, (int)OW, sh->KH, sh->KW, sh->stride_h, sh->stride_w, sh->pad_h, sh->pad_w, sh->dil_h, sh->dil_w, (int)K, groups8);
+    launch_im2col(x, x_sample_stride, panel, sh, OH, OW, K, x_samples, M, out_bf16 != 0, (hipStream_t)stream);
     return check_launch(who);
 }
 
