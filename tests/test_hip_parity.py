@@ -905,6 +905,90 @@ def test_plain_conv2d_backward_panel_vs_float64_autograd(env, shared):
         assert got.shape == w_.shape and allclose_scaled(N(got), w_.numpy(), 2e-5)
 
 
+def _random_linear_shapes():
+    rng = np.random.RandomState(1234)
+    shapes = []
+    for _ in range(28):
+        S = int(rng.randint(1, 5))
+        M = int(rng.choice([1, 2, 7, 16, 31, 33, 64, 65, 130]))
+        Nn = int(rng.choice([1, 2, 9, 15, 16, 17, 24, 31, 47, 48, 49, 80, 97]))
+        K = int(rng.choice([1, 3, 4, 5, 8, 12, 20, 32, 36, 60, 64, 68, 100, 128, 132, 200]))
+        shapes.append((S, M, Nn, K, bool(rng.randint(0, 2)), bool(rng.randint(0, 2))))
+    return shapes
+
+
+@pytest.mark.parametrize("S,M,Nn,K,bias,shared", _random_linear_shapes())
+def test_random_shapes_forward_and_backward_vs_oracle(env, S, M, Nn, K, bias, shared):
+    """Seeded sweep over ragged / tiny / unaligned shapes (every dispatch path: draw-paced tiles, narrow head,
+    generic kernel; fused and explicit-weight input gradient; tile, sample-split and narrow weight gradient):
+    exact-fp32 forward against oracle.linear on the oracle's draws, backward against oracle.linear_bwd."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    orc, dev = env["orc"], env["dev"]
+    gen = torch.Generator().manual_seed(S * 1000003 + M * 1009 + Nn * 31 + K)
+    mu = torch.randn(Nn, K, generator=gen) * 0.2
+    rho = torch.randn(Nn, K, generator=gen) * 0.3 - 2.0
+    mub = torch.randn(Nn, generator=gen) * 0.2
+    rhob = torch.randn(Nn, generator=gen) * 0.3 - 2.0
+    x = torch.randn((M, K) if shared else (S, M, K), generator=gen)
+    gy = torch.randn(S, M, Nn, generator=gen)
+    kw, kb = DrawKey(11, 3, 2, S, 5), DrawKey(11, 4, 2, S, 5)
+    xd = x.to(dev).requires_grad_(True)
+    md, rd = mu.to(dev).requires_grad_(True), rho.to(dev).requires_grad_(True)
+    mbd, rbd = (mub.to(dev).requires_grad_(True), rhob.to(dev).requires_grad_(True)) if bias else (None, None)
+    y = env["ops"].linear_sampled(xd, md, rd, mbd, rbd, kw, kb if bias else None, shared)
+    eps = [orc.eps_fill(kw.seed, kw.stream, 2 + s_, kw.epoch_host, 0, (Nn, K)) for s_ in range(S)]
+    epsb = [orc.eps_fill(kb.seed, kb.stream, 2 + s_, kb.epoch_host, 0, (Nn,)) for s_ in range(S)]
+    for s_ in range(S):
+        w = orc.sample_affine(mu.numpy(), rho.numpy(), eps[s_])
+        b_ = orc.sample_affine(mub.numpy(), rhob.numpy(), epsb[s_]) if bias else None
+        assert allclose_scaled(N(y[s_]), orc.linear(N(x if shared else x[s_]), w, b_)), (s_,)
+    grads = torch.autograd.grad(y, [xd, md, rd] + ([mbd, rbd] if bias else []), gy.to(dev))
+    want_mu, want_rho, want_x = orc.linear_bwd(mu.numpy(), rho.numpy(), x.numpy(), gy.numpy(), eps, shared)
+    assert allclose_scaled(N(grads[0]), want_x.sum(0) if shared else want_x, 2e-5)
+    assert allclose_scaled(N(grads[1]), want_mu, 2e-5)
+    assert allclose_scaled(N(grads[2]), want_rho, 2e-5)
+    if bias:
+        gmb = np.zeros(Nn)
+        grb = np.zeros(Nn)
+        for s_ in range(S):
+            cs = N(gy[s_]).astype(np.float64).sum(0)
+            a, b_ = orc.sample_affine_bwd(np.ones(Nn, np.float32), rhob.numpy(), epsb[s_])
+            gmb += cs * a
+            grb += cs * b_
+        assert allclose_scaled(N(grads[3]), gmb, 2e-5) and allclose_scaled(N(grads[4]), grb, 2e-5)
+
+
+@pytest.mark.parametrize("S,M,Nn,K,bias,shared", _random_linear_shapes()[:14])
+@pytest.mark.parametrize("acts", ["f32", "bf16"])
+def test_random_shapes_bf16_mode_vs_exact_oracle(env, S, M, Nn, K, bias, shared, acts):
+    """Same sweep in bf16 compute mode (bf16 operands, fp32 accumulate; hidden activations fp32 or bf16 where the
+    shape allows): forward and backward within 3e-2 of the output scale of the EXACT oracle."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    orc, dev = env["orc"], env["dev"]
+    if acts == "bf16" and K % 8 != 0:
+        pytest.skip("bf16 activations need K % 8 == 0 (BNN_FLAG_X_BF16)")
+    gen = torch.Generator().manual_seed(S * 1000003 + M * 1009 + Nn * 31 + K + 7)
+    mu = torch.randn(Nn, K, generator=gen) * 0.2
+    rho = torch.randn(Nn, K, generator=gen) * 0.3 - 2.0
+    x = torch.randn((M, K) if shared else (S, M, K), generator=gen)
+    gy = torch.randn(S, M, Nn, generator=gen)
+    kw = DrawKey(12, 3, 0, S, 6)
+    adt = torch.bfloat16 if acts == "bf16" else torch.float32
+    xr = x.to(adt).float()                                   # the operand the kernel really sees
+    xd = x.to(dev).to(adt).requires_grad_(True)
+    md, rd = mu.to(dev).requires_grad_(True), rho.to(dev).requires_grad_(True)
+    y = env["ops"].linear_sampled(xd, md, rd, None, None, kw, None, shared, compute="bf16", out_dtype=adt)
+    eps = [orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, (Nn, K)) for s_ in range(S)]
+    for s_ in range(S):
+        w = orc.sample_affine(mu.numpy(), rho.numpy(), eps[s_])
+        assert allclose_scaled(N(y[s_].float()), orc.linear(N(xr if shared else xr[s_]), w, None), 3e-2)
+    gx, g_mu, g_rho = torch.autograd.grad(y, (xd, md, rd), gy.to(dev).to(adt))
+    gyr = gy.to(adt).float()
+    want_mu, want_rho, want_x = orc.linear_bwd(mu.numpy(), rho.numpy(), xr.numpy(), gyr.numpy(), eps, shared)
+    assert allclose_scaled(N(gx.float()), want_x.sum(0) if shared else want_x, 3e-2)
+    assert allclose_scaled(N(g_mu), want_mu, 3e-2) and allclose_scaled(N(g_rho), want_rho, 3e-2)
+
+
 # ------------------------------------------------------------------ pruning (SURVEY 8f-3)
 def test_prune_normal_on_device(env):
     """prune/prune.py:7-22 on the device: HIP score == oracle; half of every tensor pruned to (0, -30); the
