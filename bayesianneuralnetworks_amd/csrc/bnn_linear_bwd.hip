@@ -1214,6 +1214,22 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const void *__restrict__ g, co
     }
 }
 
+// 16-B form for the common case (both bf16, n % 8 == 0, aligned): 8 elements per thread
+__global__ __launch_bounds__(256) void k_relu_bwd_bf16x8(const uint4 *__restrict__ g, const uint4 *__restrict__ y,
+                                                         uint4 *__restrict__ out, int64_t n8)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 gv = g[i], yv = y[i];
+    // bf16 > 0  <=>  sign bit clear and not (+)0: compare the 16-bit patterns as signed shorts
+    auto m2 = [](uint32_t gg, uint32_t yy) -> uint32_t {
+        const uint32_t lo = ((int16_t)(yy & 0xFFFFu) > 0) ? 0xFFFFu : 0u;
+        const uint32_t hi = ((int16_t)(yy >> 16) > 0) ? 0xFFFF0000u : 0u;
+        return gg & (lo | hi);
+    };
+    out[i] = make_uint4(m2(gv.x, yv.x), m2(gv.y, yv.y), m2(gv.z, yv.z), m2(gv.w, yv.w));
+}
+
 static inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
 }  // namespace bnn
@@ -1511,8 +1527,14 @@ int bnn_relu_backward(const void *g, const void *y, void *out, int64_t n, int fl
     if (n < 0 || n > ((int64_t)1 << 38)) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
     if (n == 0) return BNN_OK;
     const bool gh = (flags & BNN_FLAG_X_BF16) != 0, yh = (flags & BNN_FLAG_Y_BF16) != 0;
-    const dim3 grid((unsigned)((n + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
+    if (gh && yh && n % 8 == 0 && al16(g) && al16(y) && al16(out)) {
+        const int64_t n8 = n / 8;
+        hipLaunchKernelGGL(k_relu_bwd_bf16x8, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(g),
+                           reinterpret_cast<const uint4 *>(y), reinterpret_cast<uint4 *>(out), n8);
+        return check_launch(who);
+    }
+    const dim3 grid((unsigned)((n + 255) / 256));
     if (gh && yh) hipLaunchKernelGGL((k_relu_bwd<true, true>), grid, dim3(256), 0, st, g, y, out, n);
     else if (gh) hipLaunchKernelGGL((k_relu_bwd<true, false>), grid, dim3(256), 0, st, g, y, out, n);
     else if (yh) hipLaunchKernelGGL((k_relu_bwd<false, true>), grid, dim3(256), 0, st, g, y, out, n);

@@ -778,6 +778,11 @@ def test_bias_colsum_and_relu_mask_kernels(env):
         for yd in (torch.float32, torch.bfloat16):
             m = env["ops"]._relu_backward_raw(gy.to(gd), y.to(yd))
             assert torch.equal(m, gy.to(gd) * (y.to(yd) > 0).to(gd))
+    # 16-B form (both bf16, n % 8 == 0), with +-0 and denormals in y
+    g8 = torch.randn(4, 64, 48, device=dev).bfloat16()
+    y8 = torch.randn(4, 64, 48, device=dev).relu_().bfloat16()
+    y8.view(-1)[:4] = torch.tensor([0.0, -0.0, 1e-40, -1e-40], device=dev).bfloat16()
+    assert torch.equal(env["ops"]._relu_backward_raw(g8, y8), g8 * (y8 > 0).to(torch.bfloat16))
 
 
 def test_weight_gradient_is_bitwise_reproducible_and_accumulates(env):
