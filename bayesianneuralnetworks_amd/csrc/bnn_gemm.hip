@@ -485,8 +485,9 @@ static void launch_im2col(const float *x, int64_t x_sample_stride, void *panel, 
                           int64_t K, int nsx, int64_t M, bool bf, hipStream_t st)
 {
     const int64_t rows = (int64_t)nsx * M;
-    // (a one-workgroup-per-row form with a compile-time 3 x 3 window was measured: no gain at K = 1152, 1.6x
-    // slower at K = 576 -- too few threads per row)
+    // (measured and rejected: one workgroup per row with a compile-time 3 x 3 window -- no gain at K = 1152, 1.6x
+    // slower at K = 576; a 2-D launch with float-reciprocal index decode -- same at K = 1152, 1.3x slower at
+    // K = 576: the kernel is bound by its 8 scattered loads per thread, not by the index arithmetic)
     const int64_t groups8 = rows * (K / 8);
     int64_t blocks = (groups8 + 255) / 256;
     if (blocks > 65536) blocks = 65536;
