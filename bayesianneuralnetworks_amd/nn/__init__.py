@@ -6,7 +6,7 @@ from .conv import (BayesianConvNd, NormalConvNd, NormalConv1d, NormalConv2d, Nor
                    FlipOutNormalConvNd, FlipOutNormalConv1d, FlipOutNormalConv2d, FlipOutNormalConv3d,
                    MCDropoutConvNd, MCDropoutConv1d, MCDropoutConv2d, MCDropoutConv3d)
 from .loss import KLDivergence, Entropy, NormalInverseGaussianLoss, NormalInverseGaussianUncertainty
-from ._settings import set_compute, get_compute, fuse_activations
+from ._settings import set_compute, get_compute, fuse_activations, fuse_kl_gradient
 
 # the names pytorch_bayesian/nn/__init__.py:7-35 exports
 __all__ = [

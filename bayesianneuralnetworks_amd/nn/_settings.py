@@ -18,6 +18,16 @@ def get_compute():
     return _default
 
 
+def fuse_kl_gradient(enable=True):
+    """Opt-in for training loops of the form `(likelihood + KLDivergence(...)(model)).backward()` (the reference's
+    train.py:57-64): KLDivergence's backward then leaves its gradient to the layers' weight-gradient launches,
+    which add the closed form in their final store (ops._kl_pending) -- no separate KL pass, no accumulation add
+    per parameter.  Leave it off when the KL gradient is taken with torch.autograd.grad(): the parked gradient
+    reaches `.grad`, not the returned tuple."""
+    from .. import ops
+    ops.FUSE_KL_GRADIENT = bool(enable)
+
+
 def fuse_activations(module, bf16_activations=False):
     """Opt-in graph rewrite inside every torch.nn.Sequential:
 

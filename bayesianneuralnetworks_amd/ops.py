@@ -158,7 +158,9 @@ def _bf(t):
 # weight-gradient kernel adds the closed-form KL gradient in its final store (no bnn_kl_backward pass, no
 # autograd accumulation add per parameter).  Entries nobody picked up (parity-mode layers, unused layers, a
 # KL node that happened to run after the layers) are flushed at the end of the pass by an engine callback.
-FUSE_KL_GRADIENT = True
+# OPT-IN (nn.fuse_kl_gradient(True)): parking returns no gradient from the KL node itself, which is only right when
+# the pass accumulates into .grad (loss.backward()); torch.autograd.grad(kl, params) needs the default path.
+FUSE_KL_GRADIENT = False
 _kl_pending = {}
 
 

@@ -213,7 +213,8 @@ class TrainStep:
 
     def __init__(self, net, x, rank, world, use_graph):
         from bayesianneuralnetworks_amd import _lib, ops, optim, distributed as bd
-        from bayesianneuralnetworks_amd.nn import KLDivergence
+        from bayesianneuralnetworks_amd.nn import KLDivergence, fuse_kl_gradient
+        fuse_kl_gradient(True)              # loss.backward() loop: KL gradient rides in the weight-gradient launches
         from bayesianneuralnetworks_amd._rng import default_generator
         self.net, self.x, self.rank, self.world = net, x, rank, world
         dev = x.device

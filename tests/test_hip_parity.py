@@ -1001,6 +1001,52 @@ def test_random_shapes_bf16_mode_vs_exact_oracle(env, S, M, Nn, K, bias, shared,
     assert allclose_scaled(N(g_mu), want_mu, 3e-2) and allclose_scaled(N(g_rho), want_rho, 3e-2)
 
 
+def test_kl_gradient_fusion_is_opt_in_and_equivalent(env):
+    """nn.fuse_kl_gradient: off (default) KLDivergence's backward returns its own gradient (torch.autograd.grad
+    works); on, the layers' weight-gradient launches add it -- same .grad after (likelihood + kl).backward();
+    a layer that takes no part in the backward still gets its KL gradient (flush)."""
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule, KLDivergence, fuse_kl_gradient
+    dev = env["dev"]
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(24, 5, 3)
+            self.layers = torch.nn.Sequential(NormalLinear(24, 48), torch.nn.ReLU(), NormalLinear(48, 5))
+            self.unused = NormalLinear(8, 8)                     # only the KL term sees it
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    torch.manual_seed(3)
+    net = Net().to(dev)
+    net.mc_batched = True
+    x = torch.randn(16, 24, device=dev)
+    gy = torch.randn(3, 16, 5, device=dev)
+    kld = KLDivergence(number_of_batches=7)
+    # default path: functional gradient of the KL term alone
+    g = torch.autograd.grad(kld(net), list(net.parameters()))
+    assert all(t is not None and torch.isfinite(t).all() for t in g)
+    results = []
+    for fuse in (False, True):
+        fuse_kl_gradient(fuse)
+        try:
+            env["bnn"].manual_seed(9)
+            for p_ in net.parameters():
+                p_.grad = None
+            n0 = env["lib"].bnn_launch_count()
+            ys = net.forward_stacked(x, 3)
+            ((ys * gy).sum() + 2.0 * kld(net)).backward()
+            results.append(([p_.grad.clone() for p_ in net.parameters()], env["lib"].bnn_launch_count() - n0))
+        finally:
+            fuse_kl_gradient(False)
+    (g0, l0), (g1, l1) = results
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert l0 > 0 and l1 > 0          # (the saving is autograd's per-parameter accumulation adds, which are torch launches)
+    from bayesianneuralnetworks_amd import ops
+    assert not ops._kl_pending
+
+
 # ------------------------------------------------------------------ pruning (SURVEY 8f-3)
 def test_prune_normal_on_device(env):
     """prune/prune.py:7-22 on the device: HIP score == oracle; half of every tensor pruned to (0, -30); the
