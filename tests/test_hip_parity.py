@@ -71,6 +71,17 @@ def test_eps_stream_moments_and_independence(env):
     assert abs(np.corrcoef(e[0][:-1], e[0][1:])[0, 1]) < 5e-3
 
 
+def test_eps_stream_is_standard_normal_ks(env):
+    """Kolmogorov-Smirnov against N(0, 1) on 2^20 draws per stream / sample / epoch (p > 1e-3 each), and the
+    tails exist (|eps| > 4 occurs about 2^20 * 6.3e-5 = 66 times)."""
+    from scipy import stats
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    for key in (DrawKey(1, 1, 0, 1, 0), DrawKey(2 ** 63 + 5, 65535, 65535, 1, 7), DrawKey(3, 9, 4, 1, 2 ** 31)):
+        e = N(env["ops"].eps_philox((1 << 20,), key, env["dev"]))[0].astype(np.float64)
+        assert stats.kstest(e, "norm").pvalue > 1e-3
+        assert 25 < int((np.abs(e) > 4).sum()) < 130
+
+
 def test_epoch_dev_changes_the_draw(env):
     from bayesianneuralnetworks_amd._rng import DrawKey, default_generator
     from bayesianneuralnetworks_amd import _lib
