@@ -286,6 +286,9 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
             const int u_row = u / (8 * CH), u_cc = u % (8 * CH);
             const int sub = u_cc >> 3, c = u_cc & 7;
             const int n = n0 + u_row;
+            // columns >= N feed only outputs that are never stored: no draw, no LDS write (with 8 CH = 64 a wave owns
+            // whole rows, so the head's waves of rows 10 .. 15 skip their unit altogether)
+            if (n >= p.N) continue;
             const int kb = k_lo + ch * (32 * CH) + 4 * u_cc;
             if constexpr (B_MODE == B_SAMPLED) {
                 // element index from the UNclamped (n, k): columns >= N draw values nobody reads
