@@ -48,6 +48,48 @@ static inline int check_rng(const bnn_rng_t *r, int nsamples)
 }
 
 // ----- Philox4x32-10 --------------------------------------------------------------
+// A uniform value parked in a VGPR.  On gfx950 a VALU instruction that reads an SGPR issues ~1.35-1.5 x slower than
+// the all-VGPR form (tools/ubench_valu.hip: v_xor_b32 v,s,v 1.35; v_bitop3_b32 v,v,s 1.49 against 0.97 for v,v,v), so
+// the 20 round keys of a hot draw loop live in VGPRs (PhiloxKeys below).
+__device__ __forceinline__ uint32_t uniform_vgpr(uint32_t s)
+{
+    uint32_t v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+
+// The 20 round keys of one (seed) as VGPR values; built once per kernel (philox_keys) so the moves are not paid per draw.
+struct PhiloxKeys { uint32_t k0[10], k1[10]; };
+
+__device__ __forceinline__ PhiloxKeys philox_keys(uint32_t k0, uint32_t k1)
+{
+    PhiloxKeys k;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        k.k0[r] = uniform_vgpr(k0 + (uint32_t)r * 0x9E3779B9u);
+        k.k1[r] = uniform_vgpr(k1 + (uint32_t)r * 0xBB67AE85u);
+    }
+    return k;
+}
+
+// three-input xor = ONE v_bitop3_b32 (truth table 0x96, gfx950) instead of the two v_xor_b32 hipcc emits
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, const PhiloxKeys &k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        uint4 n;
+        n.x = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k.k0[r], 0x96);
+        n.y = (uint32_t)p1;
+        n.z = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k.k1[r], 0x96);
+        n.w = (uint32_t)p0;
+        c = n;
+    }
+    return c;
+}
+
+// Same function with the keys left in SGPRs (kernels that draw a handful of blocks: bias, tails).
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
@@ -55,9 +97,9 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
         uint4 n;
-        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.x = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k0, 0x96);
         n.y = (uint32_t)p1;
-        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.z = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k1, 0x96);
         n.w = (uint32_t)p0;
         c = n;
         k0 += 0x9E3779B9u;
@@ -116,6 +158,18 @@ __device__ __forceinline__ float4 eps4(const RngDev &r, uint32_t epoch_dev, uint
     return z;
 }
 
+// Same values with the round keys in VGPRs (keys = philox_keys(r.key0, r.key1), once per kernel).
+__device__ __forceinline__ float4 eps4(const RngDev &r, const PhiloxKeys &keys, uint32_t epoch_dev, uint32_t block,
+                                       uint32_t sample)
+{
+    const uint4 x = philox4x32_10(make_uint4(block, r.stream_hi | (sample & 0xFFFFu),
+                                             r.epoch_host, epoch_dev), keys);
+    float4 z;
+    box_muller(x.x, x.y, z.x, z.y);
+    box_muller(x.z, x.w, z.z, z.w);
+    return z;
+}
+
 __device__ __forceinline__ float eps1(const RngDev &r, uint32_t epoch_dev, uint64_t elem,
                                       uint32_t sample)
 {
@@ -132,9 +186,16 @@ __device__ __forceinline__ float eps1(const RngDev &r, uint32_t epoch_dev, uint6
 // (KL takes ln(sigma) and therefore uses sigma_accurate below.)
 __device__ __forceinline__ float sigma_draw(float rho)
 {
-    const float e = __builtin_amdgcn_exp2f(rho * 1.44269504088896341f);
+    // threshold without v_cmp / v_cndmask (1.5 + >= 1.35 issue slots, tools/ubench_valu.hip): softplus(min(rho, 20))
+    // <= 20 + 3e-6 < rho above the threshold, and below it softplus >= rho mathematically, so max(., rho) picks the
+    // reference's branch; it only differs (by the rounding of the log, <= 4e-6) for 15 < rho <= 20.
+    // (asm: fminf / fmaxf would each add a canonicalising v_max_f32 of the loaded rho)
+    float rc, out;
+    asm("v_min_f32 %0, 0x41a00000, %1" : "=v"(rc) : "v"(rho));
+    const float e = __builtin_amdgcn_exp2f(rc * 1.44269504088896341f);
     const float sp = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), 0.693147180559945309f, 1e-10f);
-    return rho > 20.0f ? rho : sp;                 // (rho + 1e-10 == rho in fp32 above the threshold)
+    asm("v_max_f32 %0, %1, %2" : "=v"(out) : "v"(sp), "v"(rho));
+    return out;                                    // (rho + 1e-10 == rho in fp32 above the threshold)
 }
 
 // Same value to ~1e-6 RELATIVE accuracy (used where ln(sigma) is taken: KL, and for

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(kThreads) void k_sample_affine_philox(
     const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * kThreads;
     const uint32_t edev = rng_epoch_dev(rng);
+    const PhiloxKeys keys = philox_keys(rng.key0, rng.key1);
     const int64_t nblk = (n + 3) >> 2;
     const int esz = (DT == BNN_F32) ? 4 : 2;
     for (int64_t v = tid; v < nblk; v += nthreads) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void k_sample_affine_philox(
             sg.z = sigma_draw(r.z); sg.w = sigma_draw(r.w);
         }
         for (int s = 0; s < nsamples; ++s) {
-            const float4 z = eps4(rng, edev, (uint32_t)v, rng.sample0 + (uint32_t)s);
+            const float4 z = eps4(rng, keys, edev, (uint32_t)v, rng.sample0 + (uint32_t)s);
             float4 w;
             w.x = fmaf(sg.x, z.x, m.x); w.y = fmaf(sg.y, z.y, m.y);
             w.z = fmaf(sg.z, z.z, m.z); w.w = fmaf(sg.w, z.w, m.w);

@@ -192,6 +192,8 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     const uint32_t sample = p.rng_w.sample0 + (uint32_t)s;
     uint32_t edev_w = 0;
     if constexpr (SAMPLED) edev_w = rng_epoch_dev(p.rng_w);
+    PhiloxKeys keys_w{};
+    if constexpr (SAMPLED) keys_w = philox_keys(p.rng_w.key0, p.rng_w.key1);
     const float *Bsrc = SAMPLED ? p.mu : p.Bw + (int64_t)s * p.b_sample_stride;
     // unit u of a chunk -> (row, cc): row = u / (8 CH), cc = u % (8 CH) = sub * 8 + c
     // (B_SAMPLED_T: u -> (r_local, cg) = (u / (BN/4), u % (BN/4)): reduction row, 4-column group)
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                 const int c0 = n0 + 4 * cg;                               // weight column = output column
                 // element index from the UNclamped (r, c0): columns >= N draw values nobody reads
                 const int64_t e0 = (int64_t)r * p.N + c0;
-                const float4 z = eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
+                const float4 z = eps4(p.rng_w, keys_w, edev_w, (uint32_t)(e0 >> 2), sample);
                 w.x = fmaf(sigma_draw(w_.r[i][0]), z.x, w.x);
                 w.y = fmaf(sigma_draw(w_.r[i][1]), z.y, w.y);
                 w.z = fmaf(sigma_draw(w_.r[i][2]), z.z, w.z);
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
             if constexpr (B_MODE == B_SAMPLED) {
                 // element index from the UNclamped (n, k): columns >= N draw values nobody reads
                 const int64_t e0 = (int64_t)n * p.K + kb;
-                const float4 z = eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
+                const float4 z = eps4(p.rng_w, keys_w, edev_w, (uint32_t)(e0 >> 2), sample);
                 w.x = fmaf(sigma_draw(w_.r[i][0]), z.x, w.x);
                 w.y = fmaf(sigma_draw(w_.r[i][1]), z.y, w.y);
                 w.z = fmaf(sigma_draw(w_.r[i][2]), z.z, w.z);

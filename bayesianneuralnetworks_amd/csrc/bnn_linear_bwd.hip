@@ -584,6 +584,7 @@ __global__ __launch_bounds__(2 * W_NT) void k_wgrad_bf16_dma8(const WgradParams 
     if (helper) {
         // ---------------------------------------------------------------- DMA + eps role
         const uint32_t edev = rng_epoch_dev(p.rng);
+        const PhiloxKeys keys = philox_keys(p.rng.key0, p.rng.key1);   // round keys in VGPRs (this role has registers to spare)
         uint32_t xoff[2], goff;
         {
             const int sc = lane & 15;
@@ -637,8 +638,8 @@ __global__ __launch_bounds__(2 * W_NT) void k_wgrad_bf16_dma8(const WgradParams 
                     // tiles (a, 0) and (a, 1): same k, n and n + 16
                     const int a = tile >> 1;
                     const int n = nb + (lane & 15), k = kb + a * 16 + 4 * (lane >> 4);
-                    const float4 z0 = eps4(p.rng, edev, (uint32_t)(((int64_t)n * p.K + k) >> 2), sample);
-                    const float4 z1 = eps4(p.rng, edev, (uint32_t)(((int64_t)(n + 16) * p.K + k) >> 2), sample);
+                    const float4 z0 = eps4(p.rng, keys, edev, (uint32_t)(((int64_t)n * p.K + k) >> 2), sample);
+                    const float4 z1 = eps4(p.rng, keys, edev, (uint32_t)(((int64_t)(n + 16) * p.K + k) >> 2), sample);
                     my_eps[tile * 64] = z0;
                     my_eps[(tile + 1) * 64] = z1;
                     tile += 2;
