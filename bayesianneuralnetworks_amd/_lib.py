@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbnn_hip.so")
+# BNN_HIP_LIB: another build of the same C-ABI (A/B measurements); default = the in-tree library
+LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")
 
 F32, BF16 = 0, 1
 COMPUTE_F32, COMPUTE_BF16 = 0, 1

@@ -186,16 +186,10 @@ __device__ __forceinline__ float eps1(const RngDev &r, uint32_t epoch_dev, uint6
 // (KL takes ln(sigma) and therefore uses sigma_accurate below.)
 __device__ __forceinline__ float sigma_draw(float rho)
 {
-    // threshold without v_cmp / v_cndmask (1.5 + >= 1.35 issue slots, tools/ubench_valu.hip): softplus(min(rho, 20))
-    // <= 20 + 3e-6 < rho above the threshold, and below it softplus >= rho mathematically, so max(., rho) picks the
-    // reference's branch; it only differs (by the rounding of the log, <= 4e-6) for 15 < rho <= 20.
-    // (asm: fminf / fmaxf would each add a canonicalising v_max_f32 of the loaded rho)
-    float rc, out;
-    asm("v_min_f32 %0, 0x41a00000, %1" : "=v"(rc) : "v"(rho));
-    const float e = __builtin_amdgcn_exp2f(rc * 1.44269504088896341f);
+    const float e = __builtin_amdgcn_exp2f(rho * 1.44269504088896341f);
     const float sp = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), 0.693147180559945309f, 1e-10f);
-    asm("v_max_f32 %0, %1, %2" : "=v"(out) : "v"(sp), "v"(rho));
-    return out;                                    // (rho + 1e-10 == rho in fp32 above the threshold)
+    // (the threshold as v_min / v_max instead of v_cmp / v_cndmask was measured: fused GEMM +-0, K1 stream -8 %)
+    return rho > 20.0f ? rho : sp;                 // (rho + 1e-10 == rho in fp32 above the threshold)
 }
 
 // Same value to ~1e-6 RELATIVE accuracy (used where ln(sigma) is taken: KL, and for
