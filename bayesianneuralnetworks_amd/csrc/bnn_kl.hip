@@ -58,32 +58,68 @@ __device__ __forceinline__ int find_tensor(const KlLaunch &L, int block)
 
 // PT scalars per thread: 8 (2048 per workgroup: small models stay spread over the chip) or 32 (8192: large
 // tensors -- more loads in flight per thread, 4x fewer block reductions; 64 Mi scalars: 2.3 -> see DESIGN TB/s)
-template <int PT>
+// REP > 1 (very large models): the workgroup walks REP consecutive PT-blocks and reduces ONCE -- the wave / LDS
+// reduction and the workgroup's drain are a fixed cost per workgroup (2048 -> 8192 scalars per workgroup was 2.3 ->
+// 4.1 TB/s on 64 Mi scalars); each block's fp32 thread sum is added to a double, so precision does not depend on REP.
+template <int PT, int REP = 1>
 __global__ __launch_bounds__(kKlThreads) void k_kl_partial(KlLaunch L, double *__restrict__ partials)
 {
     __shared__ double red[kKlThreads / 64];
     const int t = find_tensor(L, blockIdx.x);
     const KlTensorDev T = L.t[t];
-    const int64_t base = (int64_t)(blockIdx.x - T.first_block) * (kKlThreads * PT);
-    const float inv_ps = 1.0f / T.prior_sigma;
+    const int64_t base0 = (int64_t)(blockIdx.x - T.first_block) * (kKlThreads * PT * REP);
+    // the two uniform operands of kl_elem as VGPR values: a VALU instruction that reads an SGPR issues ~1.4 x slower
+    // on gfx950 (tools/ubench_valu.hip)
+    const float inv_ps = __uint_as_float(uniform_vgpr(__float_as_uint(1.0f / T.prior_sigma)));
+    const float pmu = __uint_as_float(uniform_vgpr(__float_as_uint(T.prior_mu)));
     const bool vec = ((reinterpret_cast<uintptr_t>(T.mu) | reinterpret_cast<uintptr_t>(T.rho)) & 15u) == 0;
+    double dacc = 0.0;
+#pragma unroll 1
+    for (int rep = 0; rep < REP; ++rep) {
+    const int64_t base = base0 + (int64_t)rep * (kKlThreads * PT);
+    if (REP > 1 && base >= T.n) break;
     float acc = 0.f;
+    if (vec && base + (int64_t)kKlThreads * PT <= T.n) {
+        // interior workgroup: 16-B loads in batches of LB (mu, rho) pairs, all requested before the first use -- with one
+        // pair per wait a thread had 32 B in flight and the stream ran at half the rate it reaches with 4 pairs
+        constexpr int LB = PT / 4 < 4 ? PT / 4 : 4;
 #pragma unroll
-    for (int it = 0; it < PT / 4; ++it) {
-        const int64_t e = base + ((int64_t)it * kKlThreads + threadIdx.x) * 4;
-        if (vec && e + 4 <= T.n) {
-            const float4 m = *reinterpret_cast<const float4 *>(T.mu + e);
-            const float4 r = *reinterpret_cast<const float4 *>(T.rho + e);
-            acc += kl_elem(m.x, r.x, T.prior_mu, inv_ps);
-            acc += kl_elem(m.y, r.y, T.prior_mu, inv_ps);
-            acc += kl_elem(m.z, r.z, T.prior_mu, inv_ps);
-            acc += kl_elem(m.w, r.w, T.prior_mu, inv_ps);
-        } else {
-            for (int j = 0; j < 4; ++j)
-                if (e + j < T.n) acc += kl_elem(T.mu[e + j], T.rho[e + j], T.prior_mu, inv_ps);
+        for (int it0 = 0; it0 < PT / 4; it0 += LB) {
+            float4 m[LB], r[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const int64_t e = base + ((int64_t)(it0 + j) * kKlThreads + threadIdx.x) * 4;
+                m[j] = *reinterpret_cast<const float4 *>(T.mu + e);
+                r[j] = *reinterpret_cast<const float4 *>(T.rho + e);
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                acc += kl_elem(m[j].x, r[j].x, pmu, inv_ps);
+                acc += kl_elem(m[j].y, r[j].y, pmu, inv_ps);
+                acc += kl_elem(m[j].z, r[j].z, pmu, inv_ps);
+                acc += kl_elem(m[j].w, r[j].w, pmu, inv_ps);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int it = 0; it < PT / 4; ++it) {
+            const int64_t e = base + ((int64_t)it * kKlThreads + threadIdx.x) * 4;
+            if (vec && e + 4 <= T.n) {
+                const float4 m = *reinterpret_cast<const float4 *>(T.mu + e);
+                const float4 r = *reinterpret_cast<const float4 *>(T.rho + e);
+                acc += kl_elem(m.x, r.x, pmu, inv_ps);
+                acc += kl_elem(m.y, r.y, pmu, inv_ps);
+                acc += kl_elem(m.z, r.z, pmu, inv_ps);
+                acc += kl_elem(m.w, r.w, pmu, inv_ps);
+            } else {
+                for (int j = 0; j < 4; ++j)
+                    if (e + j < T.n) acc += kl_elem(T.mu[e + j], T.rho[e + j], pmu, inv_ps);
+            }
         }
     }
-    double d = wave_sum((double)acc);
+    dacc += (double)acc;
+    }
+    double d = wave_sum(dacc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -194,7 +230,8 @@ int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches
     int64_t total = 0;
     for (int t = 0; t < ntensors; ++t) total += tensors[t].n;
     const bool big = total >= ((int64_t)8 << 20);                  // 8192-scalar workgroups once the chip is full anyway
-    const int64_t chunk = big ? kKlThreads * 32 : kKlChunk;
+    const bool huge = total >= ((int64_t)32 << 20);                // 32768-scalar workgroups (>= 1024 of them)
+    const int64_t chunk = huge ? kKlThreads * 128 : big ? kKlThreads * 32 : kKlChunk;
     for (int g0 = 0; g0 < ntensors; g0 += kKlMaxPerLaunch) {
         KlLaunch L{};
         const int cnt = ntensors - g0 < kKlMaxPerLaunch ? ntensors - g0 : kKlMaxPerLaunch;
@@ -210,7 +247,8 @@ int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches
             F.n[g0 + i] = s.n;
             blocks += (int32_t)((s.n + chunk - 1) / chunk);
         }
-        if (big) hipLaunchKernelGGL(k_kl_partial<32>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
+        if (huge) hipLaunchKernelGGL((k_kl_partial<32, 4>), dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
+        else if (big) hipLaunchKernelGGL(k_kl_partial<32>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
         else hipLaunchKernelGGL(k_kl_partial<8>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
         rc = check_launch("bnn_kl_forward(partial)");
         if (rc) return rc;

@@ -201,6 +201,33 @@ def test_kl_many_tensors_both_reduction_paths(env):
         assert abs(out[T_] - scalar) <= 1e-5 * (1 + abs(scalar))
 
 
+@pytest.mark.parametrize("total", [(9 << 20) + 4099, (33 << 20) + 12345])
+def test_kl_large_workgroup_paths(env, total):
+    """>= 8 Mi scalars: 8192-scalar workgroups; >= 32 Mi: 32768-scalar workgroups walking 4 blocks each.  Ragged
+    tensor ends (a last workgroup that stops after 1, 2, 3 blocks; a last block that is not full), an unaligned
+    tensor (element-wise path), against the oracle's double sums."""
+    dev = env["dev"]
+    gen = torch.Generator().manual_seed(11)
+    n_small = 8192 * 2 + 5                          # ends inside the first block of its last workgroup
+    n_odd = 32768 + 8192 * 2 + 77                   # ends inside block 3 of its second workgroup
+    sizes = [total - n_small - n_odd, n_small, n_odd]
+    mus = [torch.randn(n, generator=gen) * 0.05 for n in sizes]
+    rhos = [torch.randn(n, generator=gen) * 0.15 - 2 for n in sizes]
+    dm, dr = [m.to(dev) for m in mus], [r.to(dev) for r in rhos]
+    # third tensor as an UNALIGNED view (4-byte offset): the element-wise path inside the big-workgroup kernels
+    pad_m, pad_r = torch.zeros(sizes[2] + 1, device=dev), torch.zeros(sizes[2] + 1, device=dev)
+    pad_m[1:] = dm[2]; pad_r[1:] = dr[2]
+    dm[2], dr[2] = pad_m[1:], pad_r[1:]
+    out = N(env["ops"].kl_normal(dm, dr, [(0.0, 0.1)] * 3, 2.0))
+    again = N(env["ops"].kl_normal(dm, dr, [(0.0, 0.1)] * 3, 2.0))
+    assert np.array_equal(out, again)               # fixed summation order
+    want = [env["orc"].kl_sum(mus[t].numpy(), rhos[t].numpy(), 0.0, 0.1) for t in range(3)]
+    for t in range(3):
+        assert abs(out[t] - want[t]) <= 1e-5 * (1 + abs(want[t])), (t, out[t], want[t])
+    scalar = np.mean([w / sizes[t] for t, w in enumerate(want)]) / 2.0
+    assert abs(out[3] - scalar) <= 1e-5 * (1 + abs(scalar))
+
+
 def test_mc_mean_with_epoch_advance(env):
     """bnn_mc_sum's advance_epoch: the reduction bumps the device epoch cell in the same launch."""
     dev = env["dev"]

@@ -61,6 +61,44 @@ DEFK(k_pkmul, asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(w[i])))
 DEFK(k_log_xor, asm volatile("v_log_f32 %0, %0\n v_xor_b32 %1, %1, %0\n v_xor_b32 %1, %1, %0\n v_xor_b32 %1, %1, %0" : "+v"(a[i]), "+v"(a[(i + 4) & 7])))
 DEFK(k_mad64_xor, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0\n v_xor_b32 %1, %1, %1\n v_xor_b32 %1, %1, %1" : "=v"(w[i]), "+v"(a[i]) : "s"(seed) : "vcc"))
 
+// ---- do MFMA and VALU work of DIFFERENT waves on one SIMD overlap?  One 512-thread workgroup per CU = 2 waves per
+// SIMD (wave w -> SIMD w % 4): waves 0-3 run `mf` x 8 independent v_mfma_f32_16x16x32_bf16 per iteration, waves 4-7
+// run `va` x 8 v_fma_f32 per iteration.  mode 1: MFMA waves only, 2: VALU waves only, 3: both.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512) void k_overlap(uint32_t *out, int iters, int mode, int swap)
+{
+    const int wave = threadIdx.x >> 6;
+    const bool mfma_wave = swap ? (wave & 1) == 0 : wave < 4;       // swap: roles alternate wave by wave (same SIMD pairs differ)
+    if (mfma_wave) {
+        if (!(mode & 1)) return;
+        f32x4_t acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        bf16x8_t a, b;
+        for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x & 7); b[i] = (__bf16)1.0f; }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        }
+        float s = 0.f;
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+        out[blockIdx.x * 512 + threadIdx.x] = __float_as_uint(s);
+    } else {
+        if (!(mode & 2)) return;
+        float v[8];
+        for (int i = 0; i < 8; ++i) v[i] = (float)(threadIdx.x + i);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+        }
+        float s = 0.f;
+        for (int i = 0; i < 8; ++i) s += v[i];
+        out[blockIdx.x * 512 + threadIdx.x] = __float_as_uint(s);
+    }
+}
+
 typedef void (*kern_t)(uint32_t *, int, uint32_t);
 
 int main()
@@ -97,5 +135,19 @@ int main()
         printf("%-20s %8.3f ms  %6.2f ns per wave-group per SIMD  x%.2f of v_xor_b32 (assume 4 clk -> %.1f clk)\n", k.n, best, ns_per,
                best / base, 4.0 * best / base);
     }
+    // MFMA / VALU overlap: per iteration 8 MFMAs (8 x 16 = 128 matrix-pipe cycles at peak rate) against 32 v_fma (128 issue cycles)
+    for (int swap = 0; swap < 2; ++swap)
+        for (int mode = 1; mode <= 3; ++mode) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 5; ++rep) {
+                hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(k_overlap, dim3(256), dim3(512), 0, 0, out, 8192, mode, swap);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            printf("overlap swap=%d %-10s %8.3f ms\n", swap, mode == 1 ? "mfma only" : mode == 2 ? "valu only" : "both", best);
+        }
     return 0;
 }
