@@ -260,8 +260,18 @@ __global__ __launch_bounds__(kThreads) void k_mc_sum(const float *__restrict__ y
     if (advance_epoch && tid == 0) advance_epoch[0] += advance_inc;   // nothing in this kernel draws
     const int64_t nthreads = (int64_t)gridDim.x * kThreads;
     for (int64_t i = tid; i < n; i += nthreads) {
+        // eight loads in flight, added in sample order (a runtime-bound loop of dependent adds paid one memory round
+        // trip per sample: 4.3 us for the step's (8, 512, 10) reduction)
         float a = 0.f;
-        for (int s = 0; s < nsamples; ++s) a += y[(int64_t)s * y_sample_stride + i];
+        int s = 0;
+        for (; s + 8 <= nsamples; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = y[(int64_t)(s + j) * y_sample_stride + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += v[j];
+        }
+        for (; s < nsamples; ++s) a += y[(int64_t)s * y_sample_stride + i];
         a *= scale;
         out[i] = accumulate ? out[i] + a : a;
     }

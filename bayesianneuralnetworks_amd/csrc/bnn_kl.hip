@@ -138,9 +138,16 @@ __global__ __launch_bounds__(kKlThreads) void k_kl_final(KlFinal F, const double
     __shared__ double means[kKlMaxTensors];
     const int lane = threadIdx.x & 63;
     for (int t = threadIdx.x >> 6; t < F.ntensors; t += kKlThreads / 64) {
-        double a = 0.0;
-        for (int i = F.first[t] + lane; i < F.first[t + 1]; i += 64) a += partials[i];
-        a = wave_sum(a);
+        // four independent lane-strided chains: the loop is a chain of dependent-latency loads otherwise (703 partials
+        // of the MLP's largest tensor = 11 round trips; now 3); fixed order all the same
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int i = F.first[t] + lane;
+        const int end = F.first[t + 1];
+        for (; i + 192 < end; i += 256) {
+            a0 += partials[i]; a1 += partials[i + 64]; a2 += partials[i + 128]; a3 += partials[i + 192];
+        }
+        for (; i < end; i += 64) a0 += partials[i];
+        double a = wave_sum((a0 + a1) + (a2 + a3));
         if (lane == 0) {
             out[t] = (float)a;
             means[t] = (double)(float)(a / (double)F.n[t]);
@@ -231,7 +238,10 @@ int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches
     for (int t = 0; t < ntensors; ++t) total += tensors[t].n;
     const bool big = total >= ((int64_t)8 << 20);                  // 8192-scalar workgroups once the chip is full anyway
     const bool huge = total >= ((int64_t)32 << 20);                // 32768-scalar workgroups (>= 1024 of them)
-    const int64_t chunk = huge ? kKlThreads * 128 : big ? kKlThreads * 32 : kKlChunk;
+    // below 8 Mi scalars: 4096-scalar workgroups from 1 Mi on (the MLP's 2.4 M: step 0.1028 -> 0.1011 ms against 2048; 8192
+    // was slower again), 2048 for small models so that they still spread over the chip
+    const int small_pt = total >= ((int64_t)1 << 20) ? 16 : 8;
+    const int64_t chunk = huge ? kKlThreads * 128 : big ? kKlThreads * 32 : kKlThreads * small_pt;
     for (int g0 = 0; g0 < ntensors; g0 += kKlMaxPerLaunch) {
         KlLaunch L{};
         const int cnt = ntensors - g0 < kKlMaxPerLaunch ? ntensors - g0 : kKlMaxPerLaunch;
@@ -249,6 +259,7 @@ int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches
         }
         if (huge) hipLaunchKernelGGL((k_kl_partial<32, 4>), dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
         else if (big) hipLaunchKernelGGL(k_kl_partial<32>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
+        else if (small_pt == 16) hipLaunchKernelGGL(k_kl_partial<16>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
         else hipLaunchKernelGGL(k_kl_partial<8>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
         rc = check_launch("bnn_kl_forward(partial)");
         if (rc) return rc;
