@@ -85,6 +85,7 @@ SIGNATURES = {
     "bnn_prune_score": (_int, [_p, _p, _p, _i64, _p]),
     "bnn_kl_workspace_bytes": (_i64, [_int]),
     "bnn_kl_forward": (_int, [ctypes.POINTER(KlTensor), _int, _f, _p, _p, _p]),
+    "bnn_kl_forward_partial": (_int, [ctypes.POINTER(KlTensor), _int, _p, _p]),
     "bnn_kl_backward": (_int, [ctypes.POINTER(KlTensor), _int, _f, _p, ctypes.POINTER(_p),
                                ctypes.POINTER(_p), _int, _p]),
     "bnn_linear_forward_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64,
@@ -116,6 +117,8 @@ SIGNATURES = {
     "bnn_diag_sampler": (_int, [_p, _int, _int, _int, _p]),
     "bnn_diag_astream": (_int, [_p, _int, _int, _int, _int, _int, _int, _int, _p, _p]),
     "bnn_mc_sum": (_int, [_p, _i64, _int, _i64, _f, _p, _int, _p, ctypes.c_uint32, _p]),
+    "bnn_mc_sum_kl": (_int, [_p, _i64, _int, _i64, _f, _p, _int, _p, ctypes.c_uint32, ctypes.POINTER(KlTensor), _int, _f,
+                             _p, _p, _p]),
 }
 
 _lib = None

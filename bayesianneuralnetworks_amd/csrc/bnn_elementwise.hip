@@ -10,6 +10,7 @@
 #include <atomic>
 
 #include "bnn_device.hpp"
+#include "bnn_mc.hpp"
 
 namespace bnn {
 
@@ -250,31 +251,14 @@ __global__ __launch_bounds__(kThreads) void k_prune_score(const float *__restric
 __global__ void k_rng_advance(uint32_t *epoch_dev, uint32_t inc) { epoch_dev[0] += inc; }
 
 // ---------------------------------------------------------------- MC reduction
-__global__ __launch_bounds__(kThreads) void k_mc_sum(const float *__restrict__ y,
-                                                     int64_t y_sample_stride, int nsamples,
-                                                     int64_t n, float scale,
-                                                     float *__restrict__ out, int accumulate,
-                                                     uint32_t *advance_epoch, uint32_t advance_inc)
+__global__ __launch_bounds__(kMcThreads) void k_mc_sum(const float *__restrict__ y,
+                                                       int64_t y_sample_stride, int nsamples,
+                                                       int64_t n, float scale,
+                                                       float *__restrict__ out, int accumulate,
+                                                       uint32_t *advance_epoch, uint32_t advance_inc)
 {
-    const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (advance_epoch && tid == 0) advance_epoch[0] += advance_inc;   // nothing in this kernel draws
-    const int64_t nthreads = (int64_t)gridDim.x * kThreads;
-    for (int64_t i = tid; i < n; i += nthreads) {
-        // eight loads in flight, added in sample order (a runtime-bound loop of dependent adds paid one memory round
-        // trip per sample: 4.3 us for the step's (8, 512, 10) reduction)
-        float a = 0.f;
-        int s = 0;
-        for (; s + 8 <= nsamples; s += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = y[(int64_t)(s + j) * y_sample_stride + i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a += v[j];
-        }
-        for (; s < nsamples; ++s) a += y[(int64_t)s * y_sample_stride + i];
-        a *= scale;
-        out[i] = accumulate ? out[i] + a : a;
-    }
+    if (advance_epoch && blockIdx.x == 0 && threadIdx.x == 0) advance_epoch[0] += advance_inc;   // nothing in this kernel draws
+    mc_sum_body(y, y_sample_stride, nsamples, n, scale, out, accumulate, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------- diagnostics
@@ -454,7 +438,7 @@ int bnn_mc_sum(const float *y, int64_t y_sample_stride, int nsamples, int64_t n,
     if (!y || !out) { set_error("bnn_mc_sum: NULL pointer"); return BNN_E_NULL; }
     if (n < 0 || nsamples < 1) { set_error("bnn_mc_sum: bad extent"); return BNN_E_SHAPE; }
     if (n == 0) return advance_epoch ? bnn_rng_advance(advance_epoch, advance_inc, stream) : BNN_OK;
-    hipLaunchKernelGGL(k_mc_sum, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, y, y_sample_stride,
+    hipLaunchKernelGGL(k_mc_sum, dim3(grid_for(n)), dim3(kMcThreads), 0, (hipStream_t)stream, y, y_sample_stride,
                        nsamples, n, scale, out, accumulate, advance_epoch, advance_inc);
     return check_launch("bnn_mc_sum");
 }

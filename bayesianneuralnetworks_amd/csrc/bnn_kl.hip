@@ -6,6 +6,7 @@
 // workgroup kernel adds the partials in a fixed order (bitwise reproducible, no float
 // atomics) and forms the reference's mean-of-means / n_batches scalar.
 #include "bnn_device.hpp"
+#include "bnn_mc.hpp"
 
 namespace bnn {
 
@@ -132,8 +133,7 @@ __global__ __launch_bounds__(kKlThreads) void k_kl_partial(KlLaunch L, double *_
 // One workgroup: wave w adds the partials of tensors w, w + 4, ... in a fixed order (lane-strided,
 // then the shuffle tree: no barrier per tensor); then the scalar of KLDivergence.forward
 // (loss.py:38): mean over tensors of (sum_t / n_t), / n_batches, added in tensor order.
-__global__ __launch_bounds__(kKlThreads) void k_kl_final(KlFinal F, const double *__restrict__ partials,
-                                                         float *__restrict__ out)
+__device__ __forceinline__ void kl_final_body(const KlFinal &F, const double *__restrict__ partials, float *__restrict__ out)
 {
     __shared__ double means[kKlMaxTensors];
     const int lane = threadIdx.x & 63;
@@ -159,6 +159,30 @@ __global__ __launch_bounds__(kKlThreads) void k_kl_final(KlFinal F, const double
         for (int t = 0; t < F.ntensors; ++t) total += means[t];
         out[F.ntensors] = (float)((total / (double)F.ntensors) / (double)F.n_batches);
     }
+}
+
+__global__ __launch_bounds__(kKlThreads) void k_kl_final(KlFinal F, const double *__restrict__ partials,
+                                                         float *__restrict__ out)
+{
+    kl_final_body(F, partials, out);
+}
+
+// Tail of an MC step in ONE launch: workgroups [0, gridDim.x - 1) run the MC reduction (and bump the device epoch), the
+// last one runs KL's second pass over the partials an earlier bnn_kl_forward_partial left in the workspace.  A launch
+// costs >= 4 us on MI355X whatever it does (k_rng_advance, 1 thread: 4.1 us); the BASELINE step had three such tails.
+static_assert(kMcThreads == kKlThreads, "one block shape for both bodies");
+__global__ __launch_bounds__(kKlThreads) void k_mc_sum_kl(const float *__restrict__ y, int64_t y_sample_stride, int nsamples,
+                                                          int64_t n, float scale, float *__restrict__ out, int accumulate,
+                                                          uint32_t *advance_epoch, uint32_t advance_inc,
+                                                          KlFinal F, const double *__restrict__ partials, float *__restrict__ kl_out)
+{
+    const int nmc = (int)gridDim.x - 1;
+    if ((int)blockIdx.x == nmc) {
+        kl_final_body(F, partials, kl_out);
+        return;
+    }
+    if (advance_epoch && blockIdx.x == 0 && threadIdx.x == 0) advance_epoch[0] += advance_inc;
+    mc_sum_body(y, y_sample_stride, nsamples, n, scale, out, accumulate, (int)blockIdx.x, nmc);
 }
 
 __global__ __launch_bounds__(kKlThreads) void k_kl_backward(KlLaunch L, const float *__restrict__ upstream,
@@ -221,18 +245,11 @@ int64_t bnn_kl_workspace_bytes(int ntensors)
     return 8 * ((int64_t)(1ll << 31) / kKlChunk + kKlMaxTensors);
 }
 
-int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches, float *out,
-                   void *workspace, void *stream)
+// First pass: the partial launches (launch = true), and / or the description of where each tensor's partials lie
+// (F) -- a pure function of the tensor sizes, so bnn_mc_sum_kl can rebuild it for the second pass.
+static int kl_first_pass(const bnn_kl_tensor_t *tensors, int ntensors, double *partials, hipStream_t st, KlFinal &F, bool launch,
+                         const char *who)
 {
-    int rc = validate(tensors, ntensors, "bnn_kl_forward");
-    if (rc) return rc;
-    if (!out || !workspace) { set_error("bnn_kl_forward: NULL out / workspace"); return BNN_E_NULL; }
-    if (!(n_batches > 0.f)) { set_error("bnn_kl_forward: n_batches <= 0"); return BNN_E_RANGE; }
-    hipStream_t st = (hipStream_t)stream;
-    double *partials = reinterpret_cast<double *>(workspace);
-    KlFinal F{};
-    F.ntensors = ntensors;
-    F.n_batches = n_batches;
     int32_t pbase = 0;
     int64_t total = 0;
     for (int t = 0; t < ntensors; ++t) total += tensors[t].n;
@@ -257,17 +274,67 @@ int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches
             F.n[g0 + i] = s.n;
             blocks += (int32_t)((s.n + chunk - 1) / chunk);
         }
-        if (huge) hipLaunchKernelGGL((k_kl_partial<32, 4>), dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
-        else if (big) hipLaunchKernelGGL(k_kl_partial<32>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
-        else if (small_pt == 16) hipLaunchKernelGGL(k_kl_partial<16>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
-        else hipLaunchKernelGGL(k_kl_partial<8>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
-        rc = check_launch("bnn_kl_forward(partial)");
-        if (rc) return rc;
+        if (launch) {
+            if (huge) hipLaunchKernelGGL((k_kl_partial<32, 4>), dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
+            else if (big) hipLaunchKernelGGL(k_kl_partial<32>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
+            else if (small_pt == 16) hipLaunchKernelGGL(k_kl_partial<16>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
+            else hipLaunchKernelGGL(k_kl_partial<8>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
+            const int rc = check_launch(who);
+            if (rc) return rc;
+        }
         pbase += blocks;
     }
     F.first[ntensors] = pbase;
+    return BNN_OK;
+}
+
+int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches, float *out,
+                   void *workspace, void *stream)
+{
+    int rc = validate(tensors, ntensors, "bnn_kl_forward");
+    if (rc) return rc;
+    if (!out || !workspace) { set_error("bnn_kl_forward: NULL out / workspace"); return BNN_E_NULL; }
+    if (!(n_batches > 0.f)) { set_error("bnn_kl_forward: n_batches <= 0"); return BNN_E_RANGE; }
+    hipStream_t st = (hipStream_t)stream;
+    double *partials = reinterpret_cast<double *>(workspace);
+    KlFinal F{};
+    F.ntensors = ntensors;
+    F.n_batches = n_batches;
+    rc = kl_first_pass(tensors, ntensors, partials, st, F, true, "bnn_kl_forward(partial)");
+    if (rc) return rc;
     hipLaunchKernelGGL(k_kl_final, dim3(1), dim3(kKlThreads), 0, st, F, partials, out);
     return check_launch("bnn_kl_forward(final)");
+}
+
+int bnn_kl_forward_partial(const bnn_kl_tensor_t *tensors, int ntensors, void *workspace, void *stream)
+{
+    int rc = validate(tensors, ntensors, "bnn_kl_forward_partial");
+    if (rc) return rc;
+    if (!workspace) { set_error("bnn_kl_forward_partial: NULL workspace"); return BNN_E_NULL; }
+    KlFinal F{};
+    return kl_first_pass(tensors, ntensors, reinterpret_cast<double *>(workspace), (hipStream_t)stream, F, true,
+                         "bnn_kl_forward_partial");
+}
+
+int bnn_mc_sum_kl(const float *y, int64_t y_sample_stride, int nsamples, int64_t n, float scale, float *out, int accumulate,
+                  uint32_t *advance_epoch, uint32_t advance_inc, const bnn_kl_tensor_t *tensors, int ntensors,
+                  float n_batches, float *kl_out, const void *workspace, void *stream)
+{
+    if (!y || !out) { set_error("bnn_mc_sum_kl: NULL pointer"); return BNN_E_NULL; }
+    if (n < 1 || nsamples < 1) { set_error("bnn_mc_sum_kl: bad extent"); return BNN_E_SHAPE; }
+    int rc = validate(tensors, ntensors, "bnn_mc_sum_kl");
+    if (rc) return rc;
+    if (!kl_out || !workspace) { set_error("bnn_mc_sum_kl: NULL kl_out / workspace"); return BNN_E_NULL; }
+    if (!(n_batches > 0.f)) { set_error("bnn_mc_sum_kl: n_batches <= 0"); return BNN_E_RANGE; }
+    KlFinal F{};
+    F.ntensors = ntensors;
+    F.n_batches = n_batches;
+    kl_first_pass(tensors, ntensors, nullptr, nullptr, F, false, "bnn_mc_sum_kl");
+    int64_t b = (n + kMcThreads - 1) / kMcThreads;
+    if (b > 2048) b = 2048;
+    hipLaunchKernelGGL(k_mc_sum_kl, dim3((unsigned)b + 1), dim3(kKlThreads), 0, (hipStream_t)stream, y, y_sample_stride, nsamples, n,
+                       scale, out, accumulate, advance_epoch, advance_inc, F, reinterpret_cast<const double *>(workspace), kl_out);
+    return check_launch("bnn_mc_sum_kl");
 }
 
 int bnn_kl_backward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches,

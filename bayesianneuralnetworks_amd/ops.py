@@ -744,12 +744,43 @@ def kl_normal(mus, rhos, priors, n_batches=1.0, out=None):
     return _KLNormal.apply(n_batches, tuple(priors), out, *mus, *rhos)
 
 
+class KlDeferred:
+    """A KL whose first pass has been launched (kl_normal_begin); mc_mean(..., kl=this) runs the second pass inside the
+    MC reduction's launch and fills `out` (T + 1 floats: per-tensor sums, then the KLDivergence scalar)."""
+    __slots__ = ("arr", "T", "n_batches", "out", "ws", "keep", "done")
+
+
+def kl_normal_begin(mus, rhos, priors, n_batches=1.0, out=None):
+    """First half of kl_normal for an inference step that ends in mc_mean (no autograd): launches the partial sums
+    only.  The result lands in the returned handle's `.out` when mc_mean(..., kl=handle) has run; values are
+    bit-identical to kl_normal's."""
+    T = len(mus)
+    mus = [m.detach().contiguous() for m in mus]
+    rhos = [r.detach().contiguous() for r in rhos]
+    for m, r in zip(mus, rhos):
+        require_cuda_f32(m, "mean")
+        require_cuda_f32(r, "scale")
+    dev = mus[0].device
+    if out is None:
+        out = torch.empty(T + 1, dtype=torch.float32, device=dev)
+    else:
+        require_cuda_f32(out, "out")
+        if out.numel() != T + 1:
+            raise BnnHipError("kl_normal_begin: out must hold %d floats" % (T + 1))
+    h = KlDeferred()
+    h.arr, h.T, h.n_batches, h.out, h.ws = _kl_descs(mus, rhos, priors), T, float(n_batches), out, _kl_workspace(dev)
+    h.keep, h.done = (mus, rhos), False
+    check(_lib.load().bnn_kl_forward_partial(h.arr, T, ptr(h.ws), stream_ptr(dev)), "bnn_kl_forward_partial")
+    return h
+
+
 # --------------------------------------------------------------------------- MC reduction
-def mc_mean(y, out=None, scale=None, advance=None):
+def mc_mean(y, out=None, scale=None, advance=None, kl=None):
     """scale * sum over the leading MC axis (default scale 1/S = torch.stack(preds).mean(0),
     examples/MNIST/uncertainty.py:50).  `out` (optional, y[0].numel() floats) is written in place.
     `advance` (optional, a device epoch cell of _rng.EpsGenerator.epoch_dev) is bumped by one in the
-    same launch: the fresh-noise step of a captured MC forward without a launch of its own."""
+    same launch: the fresh-noise step of a captured MC forward without a launch of its own.
+    `kl` (optional, a KlDeferred from kl_normal_begin): that KL's second pass runs in this launch too."""
     require_cuda_f32(y, "y")
     S = y.shape[0]
     n = y[0].numel()
@@ -759,9 +790,17 @@ def mc_mean(y, out=None, scale=None, advance=None):
         require_cuda_f32(out, "out")
         if out.numel() != n:
             raise BnnHipError("mc_mean: out must hold %d floats" % n)
-    check(_lib.load().bnn_mc_sum(ptr(y), n, S, n, (1.0 / S) if scale is None else float(scale), ptr(out), 0,
-                                 ptr(advance) if advance is not None else None, 1, stream_ptr(y.device)),
-          "bnn_mc_sum")
+    sc = (1.0 / S) if scale is None else float(scale)
+    adv = ptr(advance) if advance is not None else None
+    if kl is not None:
+        # second pass of a KL begun by kl_normal_begin, as one extra workgroup of this launch
+        if kl.done:
+            raise BnnHipError("mc_mean: this KlDeferred has already been finished")
+        check(_lib.load().bnn_mc_sum_kl(ptr(y), n, S, n, sc, ptr(out), 0, adv, 1, kl.arr, kl.T, kl.n_batches,
+                                        ptr(kl.out), ptr(kl.ws), stream_ptr(y.device)), "bnn_mc_sum_kl")
+        kl.done = True
+        return out
+    check(_lib.load().bnn_mc_sum(ptr(y), n, S, n, sc, ptr(out), 0, adv, 1, stream_ptr(y.device)), "bnn_mc_sum")
     return out
 
 

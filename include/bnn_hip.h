@@ -138,6 +138,11 @@ int bnn_rng_advance(uint32_t *epoch_dev, uint32_t inc, void *stream);
 int64_t bnn_kl_workspace_bytes(int ntensors);
 int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches,
                    float *out, void *workspace, void *stream);
+/* The same result in two calls, for a step that ends in the MC reduction (examples/MNIST/uncertainty.py:50 after
+ * nn/loss.py:30-38): bnn_kl_forward_partial launches only the first pass; bnn_mc_sum_kl (below) runs the second pass
+ * as one extra workgroup of the reduction's launch.  Every launch costs >= 4 us on MI355X; this removes one from
+ * each forward.  Same tensors / workspace in both calls, stream-ordered; values bit-identical to bnn_kl_forward. */
+int bnn_kl_forward_partial(const bnn_kl_tensor_t *tensors, int ntensors, void *workspace, void *stream);
 /* Backward: for tensor t,  g_mu (+)= scale_t * (mu - mu_p)/sigma_p^2,
  *   g_rho (+)= scale_t * (sigma/sigma_p^2 - 1/sigma) * sigmoid(rho),
  * scale_t = *upstream (device scalar, may be NULL = 1) / (n_t * ntensors * n_batches). */
@@ -360,6 +365,13 @@ int bnn_prune_score(const float *mu, const float *rho, float *out, int64_t n, vo
 int bnn_mc_sum(const float *y, int64_t y_sample_stride, int nsamples, int64_t n,
                float scale, float *out, int accumulate, uint32_t *advance_epoch,
                uint32_t advance_inc, void *stream);
+
+/* bnn_mc_sum + the second pass of a KL begun by bnn_kl_forward_partial(tensors, ntensors, workspace): kl_out as `out`
+ * of bnn_kl_forward (ntensors + 1 floats). */
+int bnn_mc_sum_kl(const float *y, int64_t y_sample_stride, int nsamples, int64_t n,
+                  float scale, float *out, int accumulate, uint32_t *advance_epoch,
+                  uint32_t advance_inc, const bnn_kl_tensor_t *tensors, int ntensors,
+                  float n_batches, float *kl_out, const void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

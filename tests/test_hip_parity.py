@@ -228,6 +228,36 @@ def test_kl_large_workgroup_paths(env, total):
     assert abs(out[3] - scalar) <= 1e-5 * (1 + abs(scalar))
 
 
+def test_kl_second_pass_inside_mc_reduction(env):
+    """ops.kl_normal_begin + ops.mc_mean(kl=...) (bnn_kl_forward_partial / bnn_mc_sum_kl: KL's second pass as one extra
+    workgroup of the MC reduction) == ops.kl_normal + ops.mc_mean, bit for bit; the epoch cell is bumped once."""
+    dev = env["dev"]
+    ops = env["ops"]
+    gen = torch.Generator().manual_seed(3)
+    sizes = [1200 * 784, 1200, 1200 * 1200, 1200, 12000, 10]
+    mus = [(torch.randn(n, generator=gen) * 0.05).to(dev) for n in sizes]
+    rhos = [(torch.randn(n, generator=gen) * 0.15 - 2).to(dev) for n in sizes]
+    pri = [(0.0, 0.1)] * len(sizes)
+    y = torch.randn(8, 512, 10, device=dev)
+    cell = torch.zeros(4, dtype=torch.int32, device=dev)
+    want_kl = N(ops.kl_normal(mus, rhos, pri, 2.0))
+    want_mean = N(ops.mc_mean(y, scale=0.25))
+    out = torch.full((len(sizes) + 1,), -1.0, device=dev)
+    h = ops.kl_normal_begin(mus, rhos, pri, 2.0, out=out)
+    got_mean = N(ops.mc_mean(y, scale=0.25, advance=cell, kl=h))
+    assert np.array_equal(N(out), want_kl)
+    assert np.array_equal(got_mean, want_mean)
+    assert cell.tolist() == [1, 0, 0, 0]
+    with pytest.raises(Exception):
+        ops.mc_mean(y, kl=h)                        # a handle is finished once
+    # a large reduction (more MC workgroups than the 2048-block cap) next to a one-tensor KL
+    y2 = torch.randn(3, 700001, device=dev)
+    h2 = ops.kl_normal_begin(mus[:1], rhos[:1], pri[:1], 1.0)
+    got2 = N(ops.mc_mean(y2, kl=h2))
+    assert np.array_equal(got2, N(ops.mc_mean(y2)))
+    assert np.array_equal(N(h2.out), N(ops.kl_normal(mus[:1], rhos[:1], pri[:1], 1.0)))
+
+
 def test_mc_mean_with_epoch_advance(env):
     """bnn_mc_sum's advance_epoch: the reduction bumps the device epoch cell in the same launch."""
     dev = env["dev"]
