@@ -90,6 +90,8 @@ SIGNATURES = {
                                ctypes.POINTER(_p), _int, _p]),
     "bnn_linear_forward_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64,
                                           _i64, _int, _rngp, _rngp, _int, _int, _p]),
+    "bnn_linear_forward_sampled_kl": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64,
+                                             _i64, _int, _rngp, _rngp, _int, _int, ctypes.POINTER(KlTensor), _int, _p, _p]),
     "bnn_linear_forward": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,
                                   _int, _int, _int, _p]),
     "bnn_linear_backward_input_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int,

@@ -395,7 +395,7 @@ static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
                          const float *mu_w, const float *rho_w, const float *mu_b, const float *rho_b,
                          float *y, int64_t y_sample_stride, int64_t ldy, int64_t M, int64_t N, int64_t K,
                          int nsamples, const bnn_rng_t *rng_w, const bnn_rng_t *rng_b, bool sampled,
-                         int compute, int flags, void *stream, const char *who)
+                         int compute, int flags, void *stream, const char *who, KlPiggy *kl = nullptr)
 {
     if (M == 0 && N >= 1 && K >= 1 && nsamples >= 1) return BNN_OK;     // empty batch: nothing to do (x / y may be NULL)
     if (!x || !y || (sampled ? (!mu_w || !rho_w) : !w)) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
@@ -433,7 +433,10 @@ static int linear_common(const float *x, int64_t x_sample_stride, int64_t ldx,
     static const bool force_v1 = [] { const char *e = getenv("BNN_LINEAR_KERNEL"); return e && e[0] == 'v' && e[1] == '1'; }();
     if (p.vecA && p.vecB && !force_v1) {
         fill_workspace(p);
-        return dispatch_linear_v2(p, sampled, compute, (hipStream_t)stream, who);
+        if (kl) p.kl = *kl;                                     // carried by the narrow-layer launch if that is the one taken
+        const int rc = dispatch_linear_v2(p, sampled, compute, (hipStream_t)stream, who);
+        if (kl) kl->taken = p.kl.taken;
+        return rc;
     }
     return dispatch<A_DENSE>(p, sampled, compute, (hipStream_t)stream, who);
 }
@@ -756,6 +759,25 @@ int bnn_linear_forward_sampled(const void *x, int64_t x_sample_stride, int64_t l
     return linear_common((const float *)x, x_sample_stride, ldx, nullptr, 0, nullptr, 0, mu_w, rho_w, mu_b, rho_b, (float *)y,
                          y_sample_stride, ldy, M, N, K, nsamples, rng_w, rng_b, true, compute, flags,
                          stream, "bnn_linear_forward_sampled");
+}
+
+int bnn_linear_forward_sampled_kl(const void *x, int64_t x_sample_stride, int64_t ldx,
+                                  const float *mu_w, const float *rho_w, const float *mu_b,
+                                  const float *rho_b, void *y, int64_t y_sample_stride, int64_t ldy,
+                                  int64_t M, int64_t N, int64_t K, int nsamples, const bnn_rng_t *rng_w,
+                                  const bnn_rng_t *rng_b, int compute, int flags,
+                                  const bnn_kl_tensor_t *tensors, int ntensors, void *kl_workspace, void *stream)
+{
+    const char *who = "bnn_linear_forward_sampled_kl";
+    KlPiggy kl{};
+    const bool planned = kl_plan_piggy(tensors, ntensors, kl_workspace, kl);
+    int rc = linear_common((const float *)x, x_sample_stride, ldx, nullptr, 0, nullptr, 0, mu_w, rho_w, mu_b, rho_b, (float *)y,
+                           y_sample_stride, ldy, M, N, K, nsamples, rng_w, rng_b, true, compute, flags, stream, who,
+                           planned ? &kl : nullptr);
+    if (rc) return rc;
+    // not carried (a wide layer, an unaligned one, an empty batch, a big model): the first pass gets its own launch
+    if (!planned || !kl.taken) rc = bnn_kl_forward_partial(tensors, ntensors, kl_workspace, stream);
+    return rc;
 }
 
 int bnn_linear_forward(const float *x, int64_t x_sample_stride, int64_t ldx, const float *w,

@@ -1,6 +1,7 @@
 // bnn_gemm_params.hpp -- kernel-argument block shared by the contraction kernels.
 #pragma once
 #include "bnn_device.hpp"
+#include "bnn_kl_body.hpp"
 
 namespace bnn {
 
@@ -47,6 +48,9 @@ struct GemmParams {
     int64_t ws_max_tickets;
     float *ws_slabs;
     int64_t ws_slab_bytes;
+    // KL first pass carried by this launch (bnn_linear_forward_sampled_kl): workgroups >= gemm_grid run kl_piggy_block
+    KlPiggy kl;
+    int32_t gemm_grid;
     unsigned long long *dbg;    // diagnostic stamps (bnn_linear.hip, STAMPS build), normally NULL
     int32_t dbg_block;
 };

@@ -6,128 +6,16 @@
 // workgroup kernel adds the partials in a fixed order (bitwise reproducible, no float
 // atomics) and forms the reference's mean-of-means / n_batches scalar.
 #include "bnn_device.hpp"
+#include "bnn_kl_body.hpp"
 #include "bnn_mc.hpp"
 
 namespace bnn {
 
-constexpr int kKlThreads = 256;
-constexpr int kKlPerThread = 8;                        // 2 x float4
-constexpr int kKlChunk = kKlThreads * kKlPerThread;    // 2048 scalars per workgroup
-constexpr int kKlMaxPerLaunch = 64;
-constexpr int kKlMaxTensors = 128;
-
-struct KlTensorDev {
-    const float *mu;
-    const float *rho;
-    float *g_mu;      // backward only
-    float *g_rho;     // backward only
-    int64_t n;
-    float prior_mu, prior_sigma;
-    int32_t first_block;   // first workgroup of this tensor within the launch
-    float scale;           // backward: 1 / (n * ntensors * n_batches)
-};
-struct KlLaunch {
-    KlTensorDev t[kKlMaxPerLaunch];
-    int32_t ntensors;
-    int32_t partial_base;  // index of this launch's first partial in the workspace
-};
-struct KlFinal {
-    int32_t first[kKlMaxTensors + 1];  // partial ranges
-    int64_t n[kKlMaxTensors];
-    int32_t ntensors;
-    float n_batches;
-};
-
-__device__ __forceinline__ float kl_elem(float mu, float rho, float pm, float inv_ps)
-{
-    const float sg = sigma_accurate(rho);
-    const float r0 = sg * inv_ps;
-    const float vr = r0 * r0;
-    const float t0 = (mu - pm) * inv_ps;
-    // ln(vr) = 2 ln(r0) on the native log2 unit (relative 1e-7; |ln| is O(1) or the term is tiny)
-    const float lnvr = __builtin_amdgcn_logf(r0) * (2.0f * 0.693147180559945309f);
-    return 0.5f * (vr + t0 * t0 - 1.0f - lnvr);
-}
-
-__device__ __forceinline__ int find_tensor(const KlLaunch &L, int block)
-{
-    int t = 0;
-    for (int i = 1; i < L.ntensors; ++i)
-        if (block >= L.t[i].first_block) t = i;
-    return t;
-}
-
-// PT scalars per thread: 8 (2048 per workgroup: small models stay spread over the chip) or 32 (8192: large
-// tensors -- more loads in flight per thread, 4x fewer block reductions; 64 Mi scalars: 2.3 -> see DESIGN TB/s)
-// REP > 1 (very large models): the workgroup walks REP consecutive PT-blocks and reduces ONCE -- the wave / LDS
-// reduction and the workgroup's drain are a fixed cost per workgroup (2048 -> 8192 scalars per workgroup was 2.3 ->
-// 4.1 TB/s on 64 Mi scalars); each block's fp32 thread sum is added to a double, so precision does not depend on REP.
 template <int PT, int REP = 1>
 __global__ __launch_bounds__(kKlThreads) void k_kl_partial(KlLaunch L, double *__restrict__ partials)
 {
-    __shared__ double red[kKlThreads / 64];
     const int t = find_tensor(L, blockIdx.x);
-    const KlTensorDev T = L.t[t];
-    const int64_t base0 = (int64_t)(blockIdx.x - T.first_block) * (kKlThreads * PT * REP);
-    // the two uniform operands of kl_elem as VGPR values: a VALU instruction that reads an SGPR issues ~1.4 x slower
-    // on gfx950 (tools/ubench_valu.hip)
-    const float inv_ps = __uint_as_float(uniform_vgpr(__float_as_uint(1.0f / T.prior_sigma)));
-    const float pmu = __uint_as_float(uniform_vgpr(__float_as_uint(T.prior_mu)));
-    const bool vec = ((reinterpret_cast<uintptr_t>(T.mu) | reinterpret_cast<uintptr_t>(T.rho)) & 15u) == 0;
-    double dacc = 0.0;
-#pragma unroll 1
-    for (int rep = 0; rep < REP; ++rep) {
-    const int64_t base = base0 + (int64_t)rep * (kKlThreads * PT);
-    if (REP > 1 && base >= T.n) break;
-    float acc = 0.f;
-    if (vec && base + (int64_t)kKlThreads * PT <= T.n) {
-        // interior workgroup: 16-B loads in batches of LB (mu, rho) pairs, all requested before the first use -- with one
-        // pair per wait a thread had 32 B in flight and the stream ran at half the rate it reaches with 4 pairs
-        constexpr int LB = PT / 4 < 4 ? PT / 4 : 4;
-#pragma unroll
-        for (int it0 = 0; it0 < PT / 4; it0 += LB) {
-            float4 m[LB], r[LB];
-#pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                const int64_t e = base + ((int64_t)(it0 + j) * kKlThreads + threadIdx.x) * 4;
-                m[j] = *reinterpret_cast<const float4 *>(T.mu + e);
-                r[j] = *reinterpret_cast<const float4 *>(T.rho + e);
-            }
-#pragma unroll
-            for (int j = 0; j < LB; ++j) {
-                acc += kl_elem(m[j].x, r[j].x, pmu, inv_ps);
-                acc += kl_elem(m[j].y, r[j].y, pmu, inv_ps);
-                acc += kl_elem(m[j].z, r[j].z, pmu, inv_ps);
-                acc += kl_elem(m[j].w, r[j].w, pmu, inv_ps);
-            }
-        }
-    } else {
-#pragma unroll 1
-        for (int it = 0; it < PT / 4; ++it) {
-            const int64_t e = base + ((int64_t)it * kKlThreads + threadIdx.x) * 4;
-            if (vec && e + 4 <= T.n) {
-                const float4 m = *reinterpret_cast<const float4 *>(T.mu + e);
-                const float4 r = *reinterpret_cast<const float4 *>(T.rho + e);
-                acc += kl_elem(m.x, r.x, pmu, inv_ps);
-                acc += kl_elem(m.y, r.y, pmu, inv_ps);
-                acc += kl_elem(m.z, r.z, pmu, inv_ps);
-                acc += kl_elem(m.w, r.w, pmu, inv_ps);
-            } else {
-                for (int j = 0; j < 4; ++j)
-                    if (e + j < T.n) acc += kl_elem(T.mu[e + j], T.rho[e + j], pmu, inv_ps);
-            }
-        }
-    }
-    dacc += (double)acc;
-    }
-    double d = wave_sum(dacc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int w = 0; w < kKlThreads / 64; ++w) s += red[w];
-        partials[L.partial_base + blockIdx.x] = s;
-    }
+    kl_partial_block<PT, REP>(L.t[t], (int)blockIdx.x, L.partial_base + (int)blockIdx.x, partials);
 }
 
 // One workgroup: wave w adds the partials of tensors w, w + 4, ... in a fixed order (lane-strided,
@@ -287,6 +175,38 @@ static int kl_first_pass(const bnn_kl_tensor_t *tensors, int ntensors, double *p
     F.first[ntensors] = pbase;
     return BNN_OK;
 }
+
+}  // extern "C"
+
+namespace bnn {
+bool kl_plan_piggy(const bnn_kl_tensor_t *tensors, int ntensors, void *workspace, KlPiggy &P)
+{
+    P.nblocks = 0;
+    P.taken = 0;
+    if (!tensors || !workspace || ntensors < 1 || ntensors > kKlPiggyMax) return false;
+    if (validate(tensors, ntensors, "kl_plan_piggy")) return false;
+    int64_t total = 0;
+    for (int t = 0; t < ntensors; ++t) total += tensors[t].n;
+    if (total >= ((int64_t)8 << 20)) return false;                 // big models: their own launch fills the chip
+    const int pt = total >= ((int64_t)1 << 20) ? 16 : 8;           // == kl_first_pass's rule (the second pass rebuilds it)
+    const int64_t chunk = (int64_t)kKlThreads * pt;
+    int32_t blocks = 0;
+    for (int i = 0; i < ntensors; ++i) {
+        const bnn_kl_tensor_t &s = tensors[i];
+        P.t[i].mu = s.mu; P.t[i].rho = s.rho; P.t[i].g_mu = nullptr; P.t[i].g_rho = nullptr;
+        P.t[i].n = s.n; P.t[i].prior_mu = s.prior_mu; P.t[i].prior_sigma = s.prior_sigma;
+        P.t[i].first_block = blocks; P.t[i].scale = 0.f;
+        blocks += (int32_t)((s.n + chunk - 1) / chunk);
+    }
+    P.ntensors = ntensors;
+    P.nblocks = blocks;
+    P.pt = pt;
+    P.partials = reinterpret_cast<double *>(workspace);
+    return true;
+}
+}  // namespace bnn
+
+extern "C" {
 
 int bnn_kl_forward(const bnn_kl_tensor_t *tensors, int ntensors, float n_batches, float *out,
                    void *workspace, void *stream)

@@ -86,6 +86,16 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     constexpr bool SAMPLED = (B_MODE != B_PLAIN);
     constexpr bool BT = (B_MODE == B_SAMPLED_T);
     static_assert(!(ABF && F32), "bf16 activations only in bf16 compute mode");
+    // Narrow-layer (N <= 16) forward: its 32 workgroups leave most of the chip idle, so the launch can carry the
+    // first pass of the model's KL as extra workgroups (a launch of its own costs >= 4 us).  They use the first 256
+    // threads; the other waves retire at once (a retired wave no longer counts at the barrier).
+    constexpr bool CARRIES_KL = (B_MODE == B_SAMPLED && BN == 16 && KS == 1 && !STAMPS);
+    if constexpr (CARRIES_KL) {
+        if (p.kl.nblocks > 0 && (int)blockIdx.x >= p.gemm_grid) {
+            if (threadIdx.x < 256) kl_piggy_block(p.kl, (int)blockIdx.x - p.gemm_grid);
+            return;
+        }
+    }
     constexpr int NT = NW * 64;
     constexpr int BM = NW * RW;
     constexpr int TM = RW / 16, TN = BN / 16;
@@ -677,6 +687,13 @@ static void launch_sym(GemmParams &p, hipStream_t st)
             p.dbg_block = 100;
             hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, ABF, true>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
             return;
+        }
+    }
+    if constexpr (BMODE == B_SAMPLED && BN == 16 && KS == 1 && NW >= 4) {
+        if (p.kl.nblocks > 0 && !p.kl.taken && grid + p.kl.nblocks < 0x7FFFFFFF) {
+            p.gemm_grid = (int32_t)grid;
+            grid += p.kl.nblocks;
+            p.kl.taken = 1;
         }
     }
     hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, ABF>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);

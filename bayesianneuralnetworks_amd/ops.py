@@ -140,11 +140,26 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
     rb = _rng_struct(key_b, x2.device) if mu_b is not None else None
     flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_X_BF16 if x2.dtype == torch.bfloat16 else 0) | \
             (_lib.FLAG_Y_BF16 if out_dtype == torch.bfloat16 else 0)
+    global _kl_carry
+    h = _kl_carry
+    if h is not None and N <= 16 and not h.launched and h.out.device == x2.device:
+        # a narrow layer: its launch carries the first pass of the KL begun with kl_normal_begin(carry=True)
+        check(_lib.load().bnn_linear_forward_sampled_kl(
+            ptr(x2), x_sample_stride, K, ptr(mu_w), ptr(rho_w), ptr(mu_b), ptr(rho_b),
+            ptr(y), M * N, N, M, N, K, S, ctypes.byref(rw), ctypes.byref(rb) if rb is not None else None,
+            compute, flags, h.arr, h.T, ptr(h.ws), stream_ptr(x2.device)), "bnn_linear_forward_sampled_kl")
+        h.launched = True
+        _kl_carry = None
+        return y
     check(_lib.load().bnn_linear_forward_sampled(
         ptr(x2), x_sample_stride, K, ptr(mu_w), ptr(rho_w), ptr(mu_b), ptr(rho_b),
         ptr(y), M * N, N, M, N, K, S, ctypes.byref(rw), ctypes.byref(rb) if rb is not None else None,
         compute, flags, stream_ptr(x2.device)), "bnn_linear_forward_sampled")
     return y
+
+
+# a KlDeferred whose first pass waits for a narrow layer's launch to carry it (kl_normal_begin(carry=True))
+_kl_carry = None
 
 
 def _bf(t):
@@ -747,13 +762,16 @@ def kl_normal(mus, rhos, priors, n_batches=1.0, out=None):
 class KlDeferred:
     """A KL whose first pass has been launched (kl_normal_begin); mc_mean(..., kl=this) runs the second pass inside the
     MC reduction's launch and fills `out` (T + 1 floats: per-tensor sums, then the KLDivergence scalar)."""
-    __slots__ = ("arr", "T", "n_batches", "out", "ws", "keep", "done")
+    __slots__ = ("arr", "T", "n_batches", "out", "ws", "keep", "done", "launched")
 
 
-def kl_normal_begin(mus, rhos, priors, n_batches=1.0, out=None):
+def kl_normal_begin(mus, rhos, priors, n_batches=1.0, out=None, carry=False):
     """First half of kl_normal for an inference step that ends in mc_mean (no autograd): launches the partial sums
     only.  The result lands in the returned handle's `.out` when mc_mean(..., kl=handle) has run; values are
-    bit-identical to kl_normal's."""
+    bit-identical to kl_normal's.
+    carry=True: nothing is launched here -- the next narrow sampled linear layer (N <= 16, a classifier head, whose
+    launch leaves most CUs idle) carries the partial sums in ITS launch (bnn_linear_forward_sampled_kl); if no such
+    layer runs before mc_mean(kl=handle), mc_mean launches them itself."""
     T = len(mus)
     mus = [m.detach().contiguous() for m in mus]
     rhos = [r.detach().contiguous() for r in rhos]
@@ -769,8 +787,13 @@ def kl_normal_begin(mus, rhos, priors, n_batches=1.0, out=None):
             raise BnnHipError("kl_normal_begin: out must hold %d floats" % (T + 1))
     h = KlDeferred()
     h.arr, h.T, h.n_batches, h.out, h.ws = _kl_descs(mus, rhos, priors), T, float(n_batches), out, _kl_workspace(dev)
-    h.keep, h.done = (mus, rhos), False
+    h.keep, h.done, h.launched = (mus, rhos), False, False
+    if carry:
+        global _kl_carry
+        _kl_carry = h
+        return h
     check(_lib.load().bnn_kl_forward_partial(h.arr, T, ptr(h.ws), stream_ptr(dev)), "bnn_kl_forward_partial")
+    h.launched = True
     return h
 
 
@@ -796,6 +819,12 @@ def mc_mean(y, out=None, scale=None, advance=None, kl=None):
         # second pass of a KL begun by kl_normal_begin, as one extra workgroup of this launch
         if kl.done:
             raise BnnHipError("mc_mean: this KlDeferred has already been finished")
+        if not kl.launched:                         # no narrow layer took it along
+            global _kl_carry
+            if _kl_carry is kl:
+                _kl_carry = None
+            check(_lib.load().bnn_kl_forward_partial(kl.arr, kl.T, ptr(kl.ws), stream_ptr(y.device)), "bnn_kl_forward_partial")
+            kl.launched = True
         check(_lib.load().bnn_mc_sum_kl(ptr(y), n, S, n, sc, ptr(out), 0, adv, 1, kl.arr, kl.T, kl.n_batches,
                                         ptr(kl.out), ptr(kl.ws), stream_ptr(y.device)), "bnn_mc_sum_kl")
         kl.done = True

@@ -136,19 +136,21 @@ class Step:
         self.packed[:self.T + 1].zero_()
         self.packed.index_copy_(0, self.kl_pos, self.kl_tmp[:self.Tl])
 
-    def _kl_begin(self):
-        """KL's first pass now, its second pass inside the MC reduction's launch at the end of the step (one launch
-        less per forward; same values)."""
+    def _kl_begin(self, carry):
+        """KL's first pass now -- or (carry) inside the classifier head's launch, which leaves 7/8 of the CUs idle --
+        and its second pass inside the MC reduction's launch at the end of the step: two launches fewer per forward,
+        same values."""
         out = self.packed[:self.T + 1] if self.world == 1 else self.kl_tmp
-        return self.ops.kl_normal_begin(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=out)
+        return self.ops.kl_normal_begin(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=out, carry=carry)
 
     def _body(self):
         """KL placement (BNN_BENCH_KL): 'side' forks it at the start of the step, 'after1' forks it
         behind the first GEMM (so the GEMM is the graph's root node on the main queue), 'serial'
-        keeps everything on one stream; 'tail' (default) also keeps one stream and runs KL's second pass inside the MC
-        reduction's launch (ops.kl_normal_begin / mc_mean(kl=...))."""
+        keeps everything on one stream; 'tail' also keeps one stream and runs KL's second pass inside the MC
+        reduction's launch (ops.kl_normal_begin / mc_mean(kl=...)); 'carry' (default) additionally lets the classifier
+        head's launch carry KL's first pass."""
         dev = self.x.device
-        mode = os.environ.get("BNN_BENCH_KL", "tail")
+        mode = os.environ.get("BNN_BENCH_KL", "carry")
         with torch.no_grad():
             cur = torch.cuda.current_stream(dev)
             if mode == "side":
@@ -157,7 +159,7 @@ class Step:
                     self._kl()
             elif mode == "serial":
                 self._kl()
-            kl_h = self._kl_begin() if mode == "tail" else None
+            kl_h = self._kl_begin(mode == "carry") if mode in ("tail", "carry") else None
             hook = None
             if mode == "after1":
                 def hook(_m, _i, _o):

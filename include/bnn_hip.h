@@ -178,6 +178,18 @@ int bnn_linear_forward_sampled(const void *x, int64_t x_sample_stride, int64_t l
                                int64_t M, int64_t N, int64_t K, int nsamples,
                                const bnn_rng_t *rng_w, const bnn_rng_t *rng_b,
                                int compute, int flags, void *stream);
+/* The same layer, and in the same launch the FIRST pass of the model's KL (bnn_kl_forward_partial): a narrow layer's
+ * launch (N <= 16: a classifier head, 32 workgroups at the BASELINE shape) leaves most of MI355X's 256 CUs idle and a
+ * launch of its own costs >= 4 us, so the KL partial sums ride along as extra workgroups.  When the layer is not a
+ * narrow one on the fast path, or the model is large (>= 8 Mi scalars, > 8 tensors), the first pass is launched
+ * separately by this call -- the result is the same either way; finish with bnn_mc_sum_kl (or run bnn_kl_forward).
+ * replaces  nn/dense.py:56-60 + the first half of nn/loss.py:16-28. */
+int bnn_linear_forward_sampled_kl(const void *x, int64_t x_sample_stride, int64_t ldx,
+                                  const float *mu_w, const float *rho_w, const float *mu_b,
+                                  const float *rho_b, void *y, int64_t y_sample_stride, int64_t ldy,
+                                  int64_t M, int64_t N, int64_t K, int nsamples, const bnn_rng_t *rng_w,
+                                  const bnn_rng_t *rng_b, int compute, int flags,
+                                  const bnn_kl_tensor_t *tensors, int ntensors, void *kl_workspace, void *stream);
 /* Same contraction with the weights given (F.linear(x, w, b), dense.py:60):
  * w[s] = w + s * w_sample_stride, b[s] = b + s * b_sample_stride (b may be NULL). */
 int bnn_linear_forward(const float *x, int64_t x_sample_stride, int64_t ldx,

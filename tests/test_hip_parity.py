@@ -250,6 +250,37 @@ def test_kl_second_pass_inside_mc_reduction(env):
     assert cell.tolist() == [1, 0, 0, 0]
     with pytest.raises(Exception):
         ops.mc_mean(y, kl=h)                        # a handle is finished once
+    # carry=True: the first pass rides in a narrow layer's launch (bnn_linear_forward_sampled_kl); same bits, and the
+    # layer's own output is unchanged
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    from bayesianneuralnetworks_amd import _lib
+    x = torch.randn(8, 512, 1200, device=dev).to(torch.bfloat16)
+    mw, rw, mb, rb = mus[4].view(10, 1200), rhos[4].view(10, 1200), mus[5], rhos[5]
+    kw, kb = DrawKey(7, 1, 0, 8, 0), DrawKey(7, 2, 0, 8, 0)
+    y_ref = ops._linear_sampled_raw(x, 512 * 1200, 512, mw, rw, mb, rb, kw, kb, _lib.COMPUTE_BF16)
+    out3 = torch.full((len(sizes) + 1,), -1.0, device=dev)
+    h3 = ops.kl_normal_begin(mus, rhos, pri, 2.0, out=out3, carry=True)
+    y_wide = ops._linear_sampled_raw(x, 512 * 1200, 512, mus[2].view(1200, 1200), rhos[2].view(1200, 1200), mus[3], rhos[3],
+                                     kw, kb, _lib.COMPUTE_BF16)               # a wide layer does not take it
+    assert not h3.launched
+    before = env["lib"].bnn_launch_count()
+    y_car = ops._linear_sampled_raw(x, 512 * 1200, 512, mw, rw, mb, rb, kw, kb, _lib.COMPUTE_BF16)
+    assert h3.launched and env["lib"].bnn_launch_count() == before + 1          # ONE launch: layer + KL first pass
+    ops.mc_mean(y, kl=h3)
+    assert np.array_equal(N(out3), want_kl)
+    assert np.array_equal(N(y_car), N(y_ref))
+    # ... and a handle nobody carried is launched by mc_mean itself
+    h4 = ops.kl_normal_begin(mus, rhos, pri, 2.0, carry=True)
+    ops.mc_mean(y, kl=h4)
+    assert np.array_equal(N(h4.out), want_kl)
+    # fp32 layer (4-wave narrow kernel) carrying a small model's KL (2048-scalar workgroups)
+    xf = torch.randn(8, 64, 1200, device=dev)
+    yf_ref = ops._linear_sampled_raw(xf, 64 * 1200, 64, mw, rw, mb, rb, kw, kb, _lib.COMPUTE_F32)
+    h5 = ops.kl_normal_begin(mus[3:], rhos[3:], pri[3:], 1.0, carry=True)
+    yf = ops._linear_sampled_raw(xf, 64 * 1200, 64, mw, rw, mb, rb, kw, kb, _lib.COMPUTE_F32)
+    ops.mc_mean(y, kl=h5)
+    assert np.array_equal(N(h5.out), N(ops.kl_normal(mus[3:], rhos[3:], pri[3:], 1.0)))
+    assert np.array_equal(N(yf), N(yf_ref))
     # a large reduction (more MC workgroups than the 2048-block cap) next to a one-tensor KL
     y2 = torch.randn(3, 700001, device=dev)
     h2 = ops.kl_normal_begin(mus[:1], rhos[:1], pri[:1], 1.0)
