@@ -5,7 +5,6 @@
 // Algorithmic bytes per posterior scalar (fp32): 8 read (mu, rho) + 4 (fp32) or
 // 2 (bf16) written per draw; eps-supplied mode reads 4 more.
 #include <cstdarg>
-#include <type_traits>
 #include <cstdio>
 #include <atomic>
 
@@ -97,9 +96,9 @@ __global__ __launch_bounds__(kThreads) void k_sample_affine_eps(
 
 // ---------------------------------------------------------------- K1, Philox eps
 // MODE 0: out = mu + sigma * eps ; MODE 1: out = eps (mu / rho unused).
-// PF: the (mu, rho) of the thread's NEXT grid-stride iteration are requested before the current block is drawn, so
-// a wave keeps a load in flight while it runs its ~150 VALU instructions (more bytes in flight per CU).
-template <int DT, int MODE, bool VEC, bool PF>
+// (A branch-free 16-B loop with the next block's (mu, rho) prefetched, ragged tail separate, was measured on the 768-MiB
+// stream: 4.98 TB/s against 5.42 for this plain grid-stride loop -- not kept.  Round keys in VGPRs: no difference here.)
+template <int DT, int MODE, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_sample_affine_philox(
     const float *__restrict__ mu, const float *__restrict__ rho, void *__restrict__ out,
     int64_t n, int nsamples, int64_t out_sample_stride, RngDev rng)
@@ -107,76 +106,41 @@ __global__ __launch_bounds__(kThreads) void k_sample_affine_philox(
     const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * kThreads;
     const uint32_t edev = rng_epoch_dev(rng);
-    const PhiloxKeys keys = philox_keys(rng.key0, rng.key1);
     const int64_t nblk = (n + 3) >> 2;
-    const int64_t nvec = VEC ? (n >> 2) : 0;            // blocks [0, nvec): 16-B path; the rest element by element
     const int esz = (DT == BNN_F32) ? 4 : 2;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // all samples of Philox block v from its (mu, sigma)
-    auto emit = [&](int64_t v, const float4 &m, const float4 &sg, auto VECSTORE) {
+    for (int64_t v = tid; v < nblk; v += nthreads) {
+        const int64_t base = v << 2;
+        const bool full = base + 4 <= n;
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sg = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (MODE == 0) {
+            float4 r;
+            if (VEC && full) {
+                m = reinterpret_cast<const float4 *>(mu)[v];
+                r = reinterpret_cast<const float4 *>(rho)[v];
+            } else {
+                m.x = mu[base]; r.x = rho[base];
+                m.y = base + 1 < n ? mu[base + 1] : 0.f; r.y = base + 1 < n ? rho[base + 1] : 0.f;
+                m.z = base + 2 < n ? mu[base + 2] : 0.f; r.z = base + 2 < n ? rho[base + 2] : 0.f;
+                m.w = base + 3 < n ? mu[base + 3] : 0.f; r.w = base + 3 < n ? rho[base + 3] : 0.f;
+            }
+            sg.x = sigma_draw(r.x); sg.y = sigma_draw(r.y);
+            sg.z = sigma_draw(r.z); sg.w = sigma_draw(r.w);
+        }
         for (int s = 0; s < nsamples; ++s) {
-            const float4 z = eps4(rng, keys, edev, (uint32_t)v, rng.sample0 + (uint32_t)s);
+            const float4 z = eps4(rng, edev, (uint32_t)v, rng.sample0 + (uint32_t)s);
             float4 w;
             w.x = fmaf(sg.x, z.x, m.x); w.y = fmaf(sg.y, z.y, m.y);
             w.z = fmaf(sg.z, z.z, m.z); w.w = fmaf(sg.w, z.w, m.w);
             char *o = reinterpret_cast<char *>(out) + (int64_t)s * out_sample_stride * esz;
-            if constexpr (decltype(VECSTORE)::value) {
+            if (VEC && full) {
                 store4<DT>(o, v, w);
             } else {
-                const int64_t base = v << 2;
                 store1<DT>(o, base, w.x);
                 if (base + 1 < n) store1<DT>(o, base + 1, w.y);
                 if (base + 2 < n) store1<DT>(o, base + 2, w.z);
                 if (base + 3 < n) store1<DT>(o, base + 3, w.w);
             }
         }
-    };
-
-    // ---- 16-B path: a branch-free loop
-    int64_t v = tid;
-    if constexpr (VEC) {
-        float4 m_nx = zero4, r_nx = zero4;
-        if constexpr (MODE == 0 && PF) {
-            if (v < nvec) {
-                m_nx = reinterpret_cast<const float4 *>(mu)[v];
-                r_nx = reinterpret_cast<const float4 *>(rho)[v];
-            }
-        }
-        for (; v < nvec; v += nthreads) {
-            float4 m = zero4, sg = make_float4(1.f, 1.f, 1.f, 1.f);
-            if constexpr (MODE == 0) {
-                float4 r;
-                if constexpr (PF) {
-                    m = m_nx; r = r_nx;
-                    // clamped address instead of a branch around the loads (the last iteration re-reads its own block)
-                    const int64_t vn = v + nthreads < nvec ? v + nthreads : v;
-                    m_nx = reinterpret_cast<const float4 *>(mu)[vn];
-                    r_nx = reinterpret_cast<const float4 *>(rho)[vn];
-                } else {
-                    m = reinterpret_cast<const float4 *>(mu)[v];
-                    r = reinterpret_cast<const float4 *>(rho)[v];
-                }
-                sg.x = sigma_draw(r.x); sg.y = sigma_draw(r.y);
-                sg.z = sigma_draw(r.z); sg.w = sigma_draw(r.w);
-            }
-            emit(v, m, sg, std::true_type{});
-        }
-    }
-    // ---- element-wise path (unaligned tensors; the ragged last block of an aligned one)
-    for (; v < nblk; v += nthreads) {
-        const int64_t base = v << 2;
-        float4 m = zero4, sg = make_float4(1.f, 1.f, 1.f, 1.f);
-        if constexpr (MODE == 0) {
-            float4 r;
-            m.x = mu[base]; r.x = rho[base];
-            m.y = base + 1 < n ? mu[base + 1] : 0.f; r.y = base + 1 < n ? rho[base + 1] : 0.f;
-            m.z = base + 2 < n ? mu[base + 2] : 0.f; r.z = base + 2 < n ? rho[base + 2] : 0.f;
-            m.w = base + 3 < n ? mu[base + 3] : 0.f; r.w = base + 3 < n ? rho[base + 3] : 0.f;
-            sg.x = sigma_draw(r.x); sg.y = sigma_draw(r.y);
-            sg.z = sigma_draw(r.z); sg.w = sigma_draw(r.w);
-        }
-        emit(v, m, sg, std::false_type{});
     }
 }
 
@@ -344,7 +308,7 @@ static int launch_philox(const float *mu, const float *rho, void *out, int64_t n
     const int grid = grid_for((n + 3) / 4);
     const RngDev rd = make_rng(rng);
     // PF = true: measured equal to the plain loop on a 768-MiB stream (5.28 TB/s both); kept for small grids
-#define LAUNCH(DT, M, V) hipLaunchKernelGGL((k_sample_affine_philox<DT, M, V, true>), dim3(grid), dim3(kThreads), 0, st, mu, rho, out, n, nsamples, out_sample_stride, rd)
+#define LAUNCH(DT, M, V) hipLaunchKernelGGL((k_sample_affine_philox<DT, M, V>), dim3(grid), dim3(kThreads), 0, st, mu, rho, out, n, nsamples, out_sample_stride, rd)
     if (mode == 0) {
         if (out_dtype == BNN_F32) { if (vec) LAUNCH(BNN_F32, 0, true); else LAUNCH(BNN_F32, 0, false); }
         else { if (vec) LAUNCH(BNN_BF16, 0, true); else LAUNCH(BNN_BF16, 0, false); }
