@@ -336,7 +336,8 @@ def kernel_roofline(net, x, mode, dev, iters=50):
             "traffic": TRAFFIC_PMC.get(mode), "avg_launch_us": round(ms * 1e3, 2),
             "algorithmic_flop_per_launch": flops, "algorithmic_param_bytes_per_launch": pbytes,
             "algorithmic_bytes_per_launch": pbytes + SAMPLES * BATCH * (DIMS[1] * (2 if mode == "bf16" else 4) + DIMS[2] * 4),
-            "note": "draw-bound launch: 8 x 1.44 M eps draws at the measured 1.05 Tdraw/s VALU rate = 10.9 us floor"}
+            "note": "priced against the bf16 MFMA peak; the launch also makes 8 x 1.44 M eps draws (~10 us of VALU issue) and is bound by "
+                    "its per-SIMD issue stream / consume-phase latency chain (DESIGN.md 4): with explicit weights it takes as long"}
 
 
 def sampler_roofline(dev, iters=20):
@@ -494,7 +495,7 @@ def main():
                                    "784-1200-1200-10 NormalLinear MLP, batch 512, 8 MC samples per forward per GPU, "
                                    "exact fp32 MFMA (parity mode)",
                        "samples_per_step_per_gpu": SAMPLES, "batch": BATCH,
-                       "hip_graph": not args.no_graph,
+                       "hip_graph": not args.no_graph, "launches_per_step": 4 if (world == 1 and os.environ.get("BNN_BENCH_KL", "carry") == "carry") else None,
                        "collective": "one all-reduce of [6 KL sums, KL scalar, 512x10 prediction sum] fp32" if world > 1 else None},
         }
         if train is not None:
