@@ -450,53 +450,52 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
         lds_wait_ge(&full[ch % NB], NW * (ch / NB + 1));                // chunk ch drawn by every wave
         stamp(4);
 #ifndef BNN_NO_PIPE
-        if constexpr (!F32 && ABF && CH == 2 && S == 3) {
-            // Two k-steps per chunk, software-pipelined: the fragments of step 1 are requested BEFORE the MFMAs of step 0
-            // (a step was wait -> 5 ds_read_b128 -> 6 MFMAs, the LDS latency exposed twice per chunk).  VMEM order is
-            // unchanged up to D(kt0+3), which now follows step 0's MFMAs: it refills the stage step 0's fragments were
-            // read from, so it must not be issued before those reads have returned (the MFMAs consumed them).
-            //   queue at wait 0: D(kt0) D(kt0+1) R D(kt0+2)        -> vmcnt(2 PW + LPU) retires D(kt0)
-            //   queue at wait 1: D(kt0+1) R D(kt0+2)               -> vmcnt(PW + LPU)   retires D(kt0+1)
+        if constexpr (!F32 && ABF && CH == 2 && S == 3) {          // (CH = 8, the head: measured, no gain)
+            // The k-steps of a chunk, software-pipelined one deep: the fragments of step j+1 are requested around the MFMAs
+            // of step j (a step was wait -> ds_read_b128s -> MFMAs, the LDS latency exposed at every step; the 10-wide head
+            // has ONE MFMA per step).  The stage refill D(kt+3) moves behind the MFMAs of step j: it overwrites the stage
+            // step j's fragments were read from, so it must not be issued before those reads have returned (an MFMA that
+            // has been issued has its operands).  VMEM order per iteration: R, D(kt0+2), D(kt0+3) .. D(kt0+CH+1) as before.
+            //   wait before the reads of step 0:      queue D(kt0) D(kt0+1) R D(kt0+2)   -> vmcnt(2 PW + LPU)
+            //   ... of step 1:                        queue D(kt0+1) R D(kt0+2)          -> vmcnt(PW + LPU)
+            //   ... of step j+1 >= 2:                 queue D(kt0+j+1) D(kt0+j+2)        -> vmcnt(PW)
             const int kt0 = ch * CH;
             const uint4 *Bc = Bs0 + (ch % NB) * B_CHUNK;
+            uint4 bfr[2][TN], afr[2][TM];
+            auto load_frags = [&](int j) {
+                const uint4 *As = Aw + ((kt0 + j) % S) * A_STAGE;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bfr[j & 1][b] = Bc[j * B_SUB + bpos<false>(b * 16 + fi, fq)];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) afr[j & 1][a] = As[bpos<false>(a * 16 + fi, fq)];
+            };
             dma_A((kt0 + S - 1) % S, kt0 + S - 1);
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW + LPU) : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            uint4 b0[TN], a0[TM], b1[TN], a1[TM];
-            {
-                const uint4 *As = Aw + (kt0 % S) * A_STAGE;
+            load_frags(0);
 #pragma unroll
-                for (int b = 0; b < TN; ++b) b0[b] = Bc[bpos<false>(b * 16 + fi, fq)];
+            for (int j = 0; j < CH; ++j) {
+                if (j + 1 < CH) {
+                    if (j + 1 <= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW + LPU) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_frags(j + 1);
+                    // (no scheduling barrier here: hipcc sinks part of these reads below step j's first MFMAs to reuse
+                    // registers -- 110 VGPRs, step -2.3 %; forcing them all ahead costs 122 VGPRs and gains only 1 %)
+                }
 #pragma unroll
-                for (int a = 0; a < TM; ++a) a0[a] = As[bpos<false>(a * 16 + fi, fq)];
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[j & 1][a]),
+                                                                            __builtin_bit_cast(bf16x8, bfr[j & 1][b]), acc[a][b], 0, 0, 0);
+                if (j + 1 < CH) {
+                    // step j's MFMAs have been issued, i.e. its fragments have left LDS: the stage may be refilled
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_A((kt0 + j + S) % S, kt0 + j + S);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW + LPU) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const uint4 *As = Aw + ((kt0 + 1) % S) * A_STAGE;
-#pragma unroll
-                for (int b = 0; b < TN; ++b) b1[b] = Bc[B_SUB + bpos<false>(b * 16 + fi, fq)];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) a1[a] = As[bpos<false>(a * 16 + fi, fq)];
-            }
-            // (no scheduling barrier here: hipcc sinks part of these reads below step 0's first MFMAs to reuse registers --
-            // 110 VGPRs, step -2.3 %; forcing them all ahead costs 122 VGPRs and gains only 1 %)
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[a]), __builtin_bit_cast(bf16x8, b0[b]),
-                                                                        acc[a][b], 0, 0, 0);
-            // step 0's MFMAs have been issued, i.e. its fragments have left LDS: the stage may be refilled
-            __builtin_amdgcn_sched_barrier(0);
-            dma_A((kt0 + S) % S, kt0 + S);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[a]), __builtin_bit_cast(bf16x8, b1[b]),
-                                                                        acc[a][b], 0, 0, 0);
         } else
 #endif
         {
