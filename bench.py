@@ -36,7 +36,7 @@ PEAK_HBM_GBS = 8000.0
 # Fabric-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes
 # (profiles/r01_pmc_layer2_bf16.txt): (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 FETCH_SIZE correction
 # applied.  Not measured live (PMC passes serialise kernels); re-collect with tools/pmc.sh.
-TRAFFIC_PMC = {"bf16": 84.2e6, "f32": None}
+TRAFFIC_PMC = {"bf16": 82.7e6, "f32": None}
 
 
 def posteriors(seed=0):
