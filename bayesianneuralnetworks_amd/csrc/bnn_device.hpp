@@ -230,6 +230,17 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// (x, y) -> three packed bf16 pairs h, m, l with x = h.lo + m.lo + l.lo (+ <= 2^-27 |x|), same for y / .hi: every residual
+// is exact in fp32 (a 24-bit significand minus its leading 8 bits fits), conversions round to nearest even.
+__device__ __forceinline__ void split_bf16x3(float x, float y, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = pack_bf16x2(x, y);
+    const float rx = x - __uint_as_float(h << 16), ry = y - __uint_as_float(h & 0xFFFF0000u);
+    m = pack_bf16x2(rx, ry);
+    const float qx = rx - __uint_as_float(m << 16), qy = ry - __uint_as_float(m & 0xFFFF0000u);
+    l = pack_bf16x2(qx, qy);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v)
 {

@@ -12,6 +12,8 @@ enum { B_PLAIN = 0, B_SAMPLED = 1, B_SAMPLED_T = 2 };
 // internal epilogue flag (not part of the C-ABI flags): row m = (image, pixel) -> y[image][n][pixel], i.e. the
 // conv output in NCHW; OH * OW pixels per image, O channels
 constexpr int kFlagStoreNCHW = 1 << 16;
+// internal compute mode of the fast linear kernel (not a C-ABI value): fp32-accurate results on the bf16 MFMA
+constexpr int kComputeBf16x3 = 2;
 
 struct GemmParams {
     // A operand

@@ -83,6 +83,14 @@ template <int NW, int RW, int BN, int CH, int S, int NB, int B_MODE, int COMPUTE
 __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 {
     constexpr bool F32 = (COMPUTE == BNN_COMPUTE_F32);
+    // kComputeBf16x3 (internal): fp32-accurate contraction on the bf16 MFMA.  a = ah + am + al, three bf16 terms that
+    // hold all 24 significand bits (each residual is exact in fp32); of the nine partial products the six largest are
+    // kept -- the dropped ones are <= 2^-25 |a b|, below the rounding of one fp32 multiply -- and accumulated in fp32,
+    // smallest first.  Six 16x16x32 bf16 MFMAs (96 cycles) stand for the eight 16x16x4 fp32 ones (256 cycles) of the
+    // same block.  A stays fp32 in memory / LDS and is split at fragment load; the drawn weights are split once, at draw
+    // time, into three bf16 LDS images.
+    constexpr bool X3 = (COMPUTE == kComputeBf16x3);
+    static_assert(!(X3 && (ABF || B_MODE == B_SAMPLED_T)), "bf16x3: fp32 activations, forward only");
     constexpr bool SAMPLED = (B_MODE != B_PLAIN);
     constexpr bool BT = (B_MODE == B_SAMPLED_T);
     static_assert(!(ABF && F32), "bf16 activations only in bf16 compute mode");
@@ -105,7 +113,8 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     constexpr int PW = RW / RPP;                // DMA pieces per wave per k-step
     constexpr int A_STAGE = RW * ACH;           // uint4 per wave per stage
     constexpr int CPR = F32 ? 8 : 4;            // 16-B chunks per B row per 32-k sub-tile
-    constexpr int B_SUB = BN * CPR;             // uint4 per sub-tile
+    constexpr int B_IMG = BN * CPR;             // uint4 per 32-k sub-tile image
+    constexpr int B_SUB = B_IMG * (X3 ? 3 : 1); // uint4 per sub-tile (bf16x3: hi, mid, lo images one after the other)
     constexpr int B_CHUNK = CH * B_SUB;         // uint4 per chunk buffer
     constexpr int UPC = BN * 8 * CH;            // 4-draw units per chunk
     constexpr int UPL = (UPC + NT - 1) / NT;    // units per lane per chunk (lane t: units t, t + NT, ..)
@@ -202,8 +211,11 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     const uint32_t sample = p.rng_w.sample0 + (uint32_t)s;
     uint32_t edev_w = 0;
     if constexpr (SAMPLED) edev_w = rng_epoch_dev(p.rng_w);
+    // round keys in VGPRs where the register budget allows (20 VGPRs; the fp32 and bf16x3 instantiations have two units
+    // per lane in flight and would spill)
+    constexpr bool KEYS_V = SAMPLED && !X3 && !F32;
     PhiloxKeys keys_w{};
-    if constexpr (SAMPLED) keys_w = philox_keys(p.rng_w.key0, p.rng_w.key1);
+    if constexpr (KEYS_V) keys_w = philox_keys(p.rng_w.key0, p.rng_w.key1);
     const float *Bsrc = SAMPLED ? p.mu : p.Bw + (int64_t)s * p.b_sample_stride;
     // unit u of a chunk -> (row, cc): row = u / (8 CH), cc = u % (8 CH) = sub * 8 + c
     // (B_SAMPLED_T: u -> (r_local, cg) = (u / (BN/4), u % (BN/4)): reduction row, 4-column group)
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                 const int c0 = n0 + 4 * cg;                               // weight column = output column
                 // element index from the UNclamped (r, c0): columns >= N draw values nobody reads
                 const int64_t e0 = (int64_t)r * p.N + c0;
-                const float4 z = eps4(p.rng_w, keys_w, edev_w, (uint32_t)(e0 >> 2), sample);
+                const float4 z = KEYS_V ? eps4(p.rng_w, keys_w, edev_w, (uint32_t)(e0 >> 2), sample) : eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
                 w.x = fmaf(sigma_draw(w_.r[i][0]), z.x, w.x);
                 w.y = fmaf(sigma_draw(w_.r[i][1]), z.y, w.y);
                 w.z = fmaf(sigma_draw(w_.r[i][2]), z.z, w.z);
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
             if constexpr (B_MODE == B_SAMPLED) {
                 // element index from the UNclamped (n, k): columns >= N draw values nobody reads
                 const int64_t e0 = (int64_t)n * p.K + kb;
-                const float4 z = eps4(p.rng_w, keys_w, edev_w, (uint32_t)(e0 >> 2), sample);
+                const float4 z = KEYS_V ? eps4(p.rng_w, keys_w, edev_w, (uint32_t)(e0 >> 2), sample) : eps4(p.rng_w, edev_w, (uint32_t)(e0 >> 2), sample);
                 w.x = fmaf(sigma_draw(w_.r[i][0]), z.x, w.x);
                 w.y = fmaf(sigma_draw(w_.r[i][1]), z.y, w.y);
                 w.z = fmaf(sigma_draw(w_.r[i][2]), z.z, w.z);
@@ -319,13 +331,23 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                 o.z = __float_as_uint(w.z); o.w = __float_as_uint(w.w);
                 *reinterpret_cast<uint4 *>(tile + bpos<true>(u_row, c) * 16) = o;
             } else {
-                uint2 o;
-                o.x = pack_bf16x2(w.x, w.y);
-                o.y = pack_bf16x2(w.z, w.w);
                 // fp32 A: lane-q holds k = 4q+t, 16+4q+t  -> unit c goes to q = c & 3, half c >> 2
                 // bf16 A: lane-q holds k = 8q .. 8q+7      -> unit c goes to q = c >> 1, half c & 1
                 const int bq = ABF ? (c >> 1) : (c & 3), bh = ABF ? (c & 1) : (c >> 2);
-                *reinterpret_cast<uint2 *>(tile + bpos<false>(u_row, bq) * 16 + bh * 8) = o;
+                char *dst = tile + bpos<false>(u_row, bq) * 16 + bh * 8;
+                if constexpr (X3) {
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split_bf16x3(w.x, w.y, h0, m0, l0);
+                    split_bf16x3(w.z, w.w, h1, m1, l1);
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(dst + B_IMG * 16) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2 *>(dst + 2 * B_IMG * 16) = make_uint2(l0, l1);
+                } else {
+                    uint2 o;
+                    o.x = pack_bf16x2(w.x, w.y);
+                    o.y = pack_bf16x2(w.z, w.w);
+                    *reinterpret_cast<uint2 *>(dst) = o;
+                }
             }
         }
     };
@@ -391,6 +413,38 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ua), __uint_as_float(ub),
                                                                          acc[a][b], 0, 0, 0);
                     }
+                }
+            }
+        } else if constexpr (X3) {
+            uint4 ah[TM], am[TM], al[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = a * 16 + fi;
+                const uint4 a0 = As[row * 8 + (fq ^ (row & 7))];
+                const uint4 a1 = As[row * 8 + ((fq + 4) ^ (row & 7))];
+                split_bf16x3(__uint_as_float(a0.x), __uint_as_float(a0.y), ah[a].x, am[a].x, al[a].x);
+                split_bf16x3(__uint_as_float(a0.z), __uint_as_float(a0.w), ah[a].y, am[a].y, al[a].y);
+                split_bf16x3(__uint_as_float(a1.x), __uint_as_float(a1.y), ah[a].z, am[a].z, al[a].z);
+                split_bf16x3(__uint_as_float(a1.z), __uint_as_float(a1.w), ah[a].w, am[a].w, al[a].w);
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int pos = bpos<false>(b * 16 + fi, fq);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[pos]);
+                const bf16x8 bm = __builtin_bit_cast(bf16x8, Bs[B_IMG + pos]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, Bs[2 * B_IMG + pos]);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[a]), xm = __builtin_bit_cast(bf16x8, am[a]),
+                                 xl = __builtin_bit_cast(bf16x8, al[a]);
+                    f32x4 c = acc[a][b];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, c, 0, 0, 0);
+                    acc[a][b] = c;
                 }
             }
         } else {
@@ -763,6 +817,13 @@ static bool splitk_ok(const GemmParams &p, int bm, int bn, int ks)
     return tiles <= p.ws_max_tickets && tiles * ks * bm * bn * 4 <= p.ws_slab_bytes;
 }
 
+// BNN_F32_MFMA=native: the fp32 mode on v_mfma_f32_16x16x4_f32 (exact fp32 products); default: bf16x3
+static bool f32x3_enabled()
+{
+    static const bool on = [] { const char *e = getenv("BNN_F32_MFMA"); return !(e && e[0] == 'n'); }();
+    return on;
+}
+
 template <int BMODE, int CP>
 static void select_pc(GemmParams &p, hipStream_t st)
 {
@@ -784,6 +845,10 @@ static void select_pc(GemmParams &p, hipStream_t st)
     if (p.N <= 16) {
         if (splitk_ok(p, 64, 16, 4)) launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP, false, 4>(p, st);   // 64 x 16 tiles, split-K
         else launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP>(p, st);
+    } else if (CP == BNN_COMPUTE_F32 && f32x3_enabled() && tile == 0) {
+        // fp32 results from the bf16 MFMA (kComputeBf16x3): 256 x 80 tiles, 64-k chunks, 2 chunk buffers (three B images)
+        // (8 waves x 32 rows, which halves the B-fragment LDS reads, and 32-k chunks were measured: all within 4 %)
+        launch_sym<16, 16, 80, 2, 2, 2, BMODE, kComputeBf16x3>(p, st);
     } else if ((CP == BNN_COMPUTE_F32 && tile != 512) || tile == 256) {
         // fp32 is MFMA-bound: 256 x 80 tiles fill the chip (240 workgroups at the BASELINE shape)
         // (64-k chunks, 2-stage A ring: 0.2876 -> 0.2749 ms per fp32 step against 32-k chunks / 3 stages; the kernel

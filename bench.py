@@ -493,7 +493,7 @@ def main():
                                    "8 MC samples per forward per GPU, KL once per forward, predictive mean; "
                                    "bf16 operands / fp32 accumulate" if args.dtype == "bf16" else
                                    "784-1200-1200-10 NormalLinear MLP, batch 512, 8 MC samples per forward per GPU, "
-                                   "exact fp32 MFMA (parity mode)",
+                                   "fp32 parity mode (wide layers: bf16x3 splits on the bf16 MFMA, fp32-accurate)",
                        "samples_per_step_per_gpu": SAMPLES, "batch": BATCH,
                        "hip_graph": not args.no_graph, "launches_per_step": 4 if (world == 1 and os.environ.get("BNN_BENCH_KL", "carry") == "carry") else None,
                        "collective": "one all-reduce of [6 KL sums, KL scalar, 512x10 prediction sum] fp32" if world > 1 else None},
@@ -508,7 +508,7 @@ def main():
                 line["value"], line["ms_per_step"], line["steps"] = line["train"]["value"], line["train"]["ms_per_step"], train[2]
         if "f32" in results and args.dtype != "f32":
             line["f32"] = {"value": round(results["f32"][0], 1), "ms_per_step": round(results["f32"][1], 4),
-                           "note": "same step, exact fp32 MFMA (the 1e-5 parity mode)"}
+                           "note": "same step in the 1e-5 parity mode (fp32 operands; wide layers as bf16x3 splits on the bf16 MFMA)"}
         line["roofline"] = kernel_roofline(net, x, args.dtype, dev)
         line["roofline_sampler"] = sampler_roofline(dev)
         line["roofline_kl"] = kl_roofline(dev)

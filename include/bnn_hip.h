@@ -54,7 +54,11 @@ enum { BNN_F32 = 0, BNN_BF16 = 1 };
 
 /* Compute mode of the contraction kernels. */
 enum {
-    BNN_COMPUTE_F32 = 0,  /* v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate */
+    BNN_COMPUTE_F32 = 0,  /* fp32 operands, fp32 accumulate; the 1e-5 parity mode.  Wide forward layers on the fast path run
+                           * it as three-way bf16 splits on v_mfma_f32_16x16x32_bf16 (a = ah + am + al exactly; the six
+                           * largest partial products, dropped terms <= 2^-25 |a b|, i.e. below one fp32 rounding) --
+                           * 1.4 x faster than v_mfma_f32_16x16x4_f32, which everything else in this mode uses and which
+                           * BNN_F32_MFMA=native (environment) selects everywhere */
     BNN_COMPUTE_BF16 = 1  /* operands rounded to bf16 (RNE), v_mfma_f32_16x16x32_bf16, fp32 accumulate */
 };
 

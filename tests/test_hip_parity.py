@@ -289,6 +289,30 @@ def test_kl_second_pass_inside_mc_reduction(env):
     assert np.array_equal(N(h2.out), N(ops.kl_normal(mus[:1], rhos[:1], pri[:1], 1.0)))
 
 
+def test_f32_mode_bf16x3_accuracy(env):
+    """The fp32 mode's wide forward layers run as three-way bf16 splits on the bf16 MFMA (kComputeBf16x3).  Against a
+    float64 contraction of the same fp32 operands: error <= 2e-6 of the output scale at K = 1200 (what a k-ordered fp32
+    fmaf chain gives: ~3.5e-7 * sum|a b| / scale) -- on values with a wide dynamic range and exact cancellations, where
+    a plain bf16 contraction (compute='bf16') is three orders of magnitude worse."""
+    dev = env["dev"]
+    ops = env["ops"]
+    gen = torch.Generator().manual_seed(21)
+    S, M, K, Nn = 2, 512, 1200, 1200
+    x = torch.randn(S, M, K, generator=gen) * torch.exp(torch.randn(S, M, K, generator=gen) * 2.0)     # wide dynamic range
+    w = torch.randn(S, Nn, K, generator=gen) * 0.05
+    w[:, :, 1::2] = -w[:, :, 0::2] * (1 + 2.0 ** -12)                                                    # near-cancelling pairs
+    x[:, :, 1::2] = x[:, :, 0::2]
+    b = torch.randn(S, Nn, generator=gen)
+    want = torch.einsum("smk,snk->smn", x.double(), w.double()) + b.double()[:, None, :]
+    scale = float(torch.einsum("smk,snk->smn", x.double().abs(), w.double().abs()).mean())
+    y = ops.linear_plain(x.to(dev), w.to(dev), b.to(dev), False, "f32").cpu().double()
+    err = float((y - want).abs().max())
+    assert err <= 2e-6 * scale * 8, (err, scale)            # max over 1.2 M outputs vs the MEAN sum|a b|: factor 8 head-room
+    yb = ops.linear_plain(x.to(dev), w.to(dev), b.to(dev), False, "bf16").cpu().double()
+    errb = float((yb - want).abs().max())
+    assert errb > 100 * err                                  # the test would notice a silent fall-back to one bf16 term
+
+
 def test_mc_mean_with_epoch_advance(env):
     """bnn_mc_sum's advance_epoch: the reduction bumps the device epoch cell in the same launch."""
     dev = env["dev"]
