@@ -14,10 +14,16 @@ mub = torch.zeros(N, device=dev); rhob = torch.full((N,), -2.0, device=dev)
 y = torch.empty(S, M, N, device=dev)
 kw = ops._rng_struct(DrawKey(1, 1, 0, S, 0), dev); kb = ops._rng_struct(DrawKey(1, 2, 0, S, 0), dev)
 st = _lib.stream_ptr(dev)
-for comp, name in ((0, "f32"), (1, "bf16")):
+w = (torch.randn(S, N, K, device=dev) * 0.02)
+for comp, name in ((0, "f32"), (1, "bf16"), (10, "f32 draw-once"), (11, "bf16 draw-once")):
+    def run_once(c=comp - 10):
+        # K1 materialises W_s (fp32), then the same kernel with explicit weights
+        ww = ops._sample_affine_philox_raw(mu.view(-1), rho.view(-1), DrawKey(1, 1, 0, S, 0)).view(S, N, K)
+        lib.bnn_linear_forward(_lib.ptr(x), 0, K, _lib.ptr(ww), N * K, None, 0, _lib.ptr(y), M * N, N, M, N, K, S, c, 0, st)
     def run():
         lib.bnn_linear_forward_sampled(_lib.ptr(x), 0, K, _lib.ptr(mu), _lib.ptr(rho), _lib.ptr(mub), _lib.ptr(rhob),
                                        _lib.ptr(y), M * N, N, M, N, K, S, ctypes.byref(kw), ctypes.byref(kb), comp, 0, st)
+    if comp >= 10: run = run_once
     for _ in range(2): run()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
