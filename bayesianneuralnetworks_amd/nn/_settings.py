@@ -1,6 +1,7 @@
 """Compute-mode switch of the contraction kernels.
 
-'f32'  : v_mfma_f32_16x16x4_f32, exact fp32 products -- the parity path (1e-5 vs the reference);
+'f32'  : fp32 operands and accumulation -- the parity path (1e-5 vs the reference); wide forward layers run as three-way
+        bf16 splits on the bf16 MFMA (fp32-accurate, csrc/bnn_linear.hip kComputeBf16x3), the rest on v_mfma_f32_16x16x4_f32;
 'bf16' : operands rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16) -- the
          throughput configuration BASELINE.json names (tolerance stated in tests/DESIGN.md).
 """

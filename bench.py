@@ -10,7 +10,7 @@ predictive mean over the samples, and -- for N > 1 -- ONE all-reduce over RCCL o
 
 Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel, measured live with
 events on the launch stream), `cpu_baseline` (torch-CPU port of the reference, N = 1 only),
-`f32` (same step in the exact-fp32 parity mode), `train` (N = 1: the reference's training-loop
+`f32` (same step in the fp32 parity mode), `train` (N = 1: the reference's training-loop
 body, examples/MNIST/train.py:53-65, on the same model -- forward, KL, cross-entropy, HIP
 backward, Adam).  `--mode train` makes the training step the headline value
 (N > 1: MC samples sharded as in the forward, gradients all-reduced in overlapped buckets).
