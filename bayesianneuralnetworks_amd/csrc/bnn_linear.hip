@@ -844,6 +844,8 @@ static void select_pc(GemmParams &p, hipStream_t st)
     }
     if (p.N <= 16) {
         if (splitk_ok(p, 64, 16, 4)) launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP, false, 4>(p, st);   // 64 x 16 tiles, split-K
+        // fp32 mode: the bf16 head's shape (128 x 16 tiles, 256-k chunks) on bf16x3 splits (fp32 step 0.1927 -> 0.1901 ms)
+        else if (CP == BNN_COMPUTE_F32 && f32x3_enabled()) launch_sym<8, 16, 16, 8, 3, 4, BMODE, kComputeBf16x3>(p, st);
         else launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP>(p, st);
     } else if (CP == BNN_COMPUTE_F32 && f32x3_enabled() && tile == 0) {
         // fp32 results from the bf16 MFMA (kComputeBf16x3): 256 x 80 tiles, 64-k chunks, 2 chunk buffers (three B images)
