@@ -849,7 +849,8 @@ static void select_pc(GemmParams &p, hipStream_t st)
         else launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP>(p, st);
     } else if (CP == BNN_COMPUTE_F32 && f32x3_enabled() && tile == 0) {
         // fp32 results from the bf16 MFMA (kComputeBf16x3): 256 x 80 tiles, 64-k chunks, 2 chunk buffers (three B images)
-        // (8 waves x 32 rows, which halves the B-fragment LDS reads, and 32-k chunks were measured: all within 4 %)
+        // (8 waves x 32 rows, which halves the B-fragment LDS reads, and 32-k chunks were measured: all within 4 %; 512 x 48
+        // tiles with 32-k chunks, which draw every weight once: 6 % slower)
         launch_sym<16, 16, 80, 2, 2, 2, BMODE, kComputeBf16x3>(p, st);
     } else if ((CP == BNN_COMPUTE_F32 && tile != 512) || tile == 256) {
         // fp32 is MFMA-bound: 256 x 80 tiles fill the chip (240 workgroups at the BASELINE shape)
