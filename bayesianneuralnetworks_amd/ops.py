@@ -140,12 +140,12 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
     rb = _rng_struct(key_b, x2.device) if mu_b is not None else None
     flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_X_BF16 if x2.dtype == torch.bfloat16 else 0) | \
             (_lib.FLAG_Y_BF16 if out_dtype == torch.bfloat16 else 0)
-    if (compute == _lib.COMPUTE_F32 and M >= DRAW_ONCE_MIN_ROWS and N > 16 and K % 4 == 0 and
-            x2.dtype == torch.float32 and out_dtype == torch.float32 and mu_w.data_ptr() % 16 == 0 and rho_w.data_ptr() % 16 == 0):
-        # Large batch in the fp32 mode: the fused kernel's 256-row tiles would re-draw every weight M / 256 times, and the
-        # draw is what it is made of -- so the weights of the S samples are drawn ONCE by K1 (same DrawKey -> the same
-        # values, bit for bit) and the same kernel runs on explicit weights (configs[4] layer, 4096 x 4096 at batch 4096:
-        # 111 -> 144 TFLOP/s).  S * N * K * 4 bytes of scratch; the backward re-creates the draws from the keys as always.
+    if (M >= DRAW_ONCE_MIN_ROWS and N > 16 and K % 8 == 0 and mu_w.data_ptr() % 16 == 0 and rho_w.data_ptr() % 16 == 0):
+        # Large batch: the fused kernel's 256- / 512-row tiles would re-draw every weight M / 256 (M / 512) times, and at
+        # that size the draw is what the launch is made of -- so the weights of the S samples are drawn ONCE by K1 (same
+        # DrawKey -> the same values, bit for bit) and the same kernel runs on explicit weights (configs[4] layer, 4096 x
+        # 4096 at batch 4096: fp32 mode 111 -> 144 TFLOP/s, bf16 mode 310 -> 369).  S * N * K * 4 bytes of scratch; the
+        # backward re-creates the draws from the keys as always.
         w = _sample_affine_philox_raw(mu_w.reshape(-1), rho_w.reshape(-1), key_w)
         b = _sample_affine_philox_raw(mu_b, rho_b, key_b) if mu_b is not None else None
         check(_lib.load().bnn_linear_forward(ptr(x2), x_sample_stride, K, ptr(w), N * K, ptr(b), N, ptr(y), M * N, N, M, N, K, S,
@@ -171,7 +171,7 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
 
 # a KlDeferred whose first pass waits for a narrow layer's launch to carry it (kl_normal_begin(carry=True))
 _kl_carry = None
-# fp32 mode: from this many rows per sample on, a sampled linear layer draws its weights once (K1) instead of in the GEMM
+# from this many rows per sample on, a sampled linear layer draws its weights once (K1) instead of in the GEMM
 DRAW_ONCE_MIN_ROWS = 2048
 
 

@@ -313,9 +313,11 @@ def test_f32_mode_bf16x3_accuracy(env):
     assert errb > 100 * err                                  # the test would notice a silent fall-back to one bf16 term
 
 
-def test_f32_large_batch_draws_once(env):
-    """fp32 mode, >= ops.DRAW_ONCE_MIN_ROWS rows: the weights are drawn once by K1 and the kernel runs on explicit weights --
-    the same bits as the fused in-kernel draw (same DrawKey), ReLU and bias included; gradients unchanged."""
+@pytest.mark.parametrize("mode", ["f32", "bf16", "bf16_act"])
+def test_large_batch_draws_once(env, mode):
+    """>= ops.DRAW_ONCE_MIN_ROWS rows: the weights are drawn once by K1 and the kernel runs on explicit weights -- the
+    same bits as the fused in-kernel draw (same DrawKey), ReLU and bias included; fp32 mode, bf16 mode, bf16 mode with
+    bf16 activations in and out."""
     from bayesianneuralnetworks_amd._rng import DrawKey
     from bayesianneuralnetworks_amd import _lib
     dev = env["dev"]
@@ -326,18 +328,22 @@ def test_f32_large_batch_draws_once(env):
     mu, rho = (torch.randn(Nn, K, generator=gen) * 0.05).to(dev), (torch.randn(Nn, K, generator=gen) * 0.15 - 2).to(dev)
     mb, rb = torch.randn(Nn, generator=gen).to(dev), (torch.randn(Nn, generator=gen) * 0.15 - 2).to(dev)
     kw, kb = DrawKey(5, 1, 0, S, 0), DrawKey(5, 2, 0, S, 0)
+    comp = _lib.COMPUTE_F32 if mode == "f32" else _lib.COMPUTE_BF16
+    odt = torch.bfloat16 if mode == "bf16_act" else torch.float32
+    if mode == "bf16_act":
+        x = x.bfloat16()
     old = ops.DRAW_ONCE_MIN_ROWS
     try:
         ops.DRAW_ONCE_MIN_ROWS = 1 << 30
-        fused = ops._linear_sampled_raw(x, M * K, M, mu, rho, mb, rb, kw, kb, _lib.COMPUTE_F32, relu=True)
+        fused = ops._linear_sampled_raw(x, M * K, M, mu, rho, mb, rb, kw, kb, comp, relu=True, out_dtype=odt)
         ops.DRAW_ONCE_MIN_ROWS = 2048
         before = env["lib"].bnn_launch_count()
-        once = ops._linear_sampled_raw(x, M * K, M, mu, rho, mb, rb, kw, kb, _lib.COMPUTE_F32, relu=True)
+        once = ops._linear_sampled_raw(x, M * K, M, mu, rho, mb, rb, kw, kb, comp, relu=True, out_dtype=odt)
         assert env["lib"].bnn_launch_count() == before + 3           # K1 (weights), K1 (bias), the contraction
     finally:
         ops.DRAW_ONCE_MIN_ROWS = old
-    assert np.array_equal(N(once), N(fused))
-    assert float(once.min()) == 0.0                                    # the fused ReLU ran
+    assert np.array_equal(N(once.float()), N(fused.float()))
+    assert float(once.float().min()) == 0.0                            # the fused ReLU ran
 
 
 def test_mc_mean_with_epoch_advance(env):
