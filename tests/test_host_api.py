@@ -52,6 +52,37 @@ def test_cuda_only_ops_refuse_cpu_tensors():
     from bayesianneuralnetworks_amd import ops
     with pytest.raises(_lib.BnnHipError):
         ops.sigma(torch.zeros(4))
+    # the two-halves KL and the MC reduction that finishes it: no CPU path either, and nothing is left pending
+    with pytest.raises(_lib.BnnHipError):
+        ops.kl_normal_begin([torch.zeros(8)], [torch.zeros(8)], [(0.0, 0.1)], carry=True)
+    assert ops._kl_carry is None
+    with pytest.raises(_lib.BnnHipError):
+        ops.mc_mean(torch.zeros(2, 4))
+
+
+def test_new_entry_points_reject_bad_arguments_without_launching():
+    """bnn_kl_forward_partial / bnn_mc_sum_kl / bnn_linear_forward_sampled_kl: argument errors are negative codes with a
+    message, before anything touches the GPU (runs without one)."""
+    lib = _lib.load()
+    n0 = lib.bnn_launch_count()
+    one = ctypes.c_void_p(16)
+    t = (_lib.KlTensor * 1)()
+    t[0].mu, t[0].rho, t[0].n, t[0].prior_mu, t[0].prior_sigma = 16, 16, 8, 0.0, 0.1
+    assert lib.bnn_kl_forward_partial(None, 1, one, None) < 0
+    assert lib.bnn_kl_forward_partial(t, 1, None, None) < 0
+    assert b"workspace" in lib.bnn_last_error()
+    t[0].prior_sigma = 0.0
+    assert lib.bnn_kl_forward_partial(t, 1, one, None) < 0
+    assert b"prior_sigma" in lib.bnn_last_error()
+    t[0].prior_sigma = 0.1
+    assert lib.bnn_mc_sum_kl(None, 8, 2, 8, 1.0, one, 0, None, 0, t, 1, 1.0, one, one, None) < 0
+    assert lib.bnn_mc_sum_kl(one, 8, 2, 8, 1.0, one, 0, None, 0, t, 1, 0.0, one, one, None) < 0
+    assert b"n_batches" in lib.bnn_last_error()
+    assert lib.bnn_mc_sum_kl(one, 8, 2, 8, 1.0, one, 0, None, 0, t, 1, 1.0, None, one, None) < 0
+    # the layer's own argument checks come first
+    assert lib.bnn_linear_forward_sampled_kl(None, 0, 8, one, one, None, None, one, 0, 8, 4, 8, 8, 1, None, None, 0, 0,
+                                             t, 1, one, None) < 0
+    assert lib.bnn_launch_count() == n0
 
 
 def test_exports_match_reference_names():
