@@ -66,9 +66,8 @@ class KLDivergence(Module):
             else:
                 other.append(self.compute_kl(param, module, type))
         if fused and not other:
-            out = ops.kl_normal([p.mean for p, _ in fused], [p.scale for p, _ in fused],
-                                [sn for _, sn in fused], self.n_batches)
-            return out[len(fused)]
+            return ops.kl_normal_scalar([p.mean for p, _ in fused], [p.scale for p, _ in fused],
+                                        [sn for _, sn in fused], self.n_batches)
         means = list(other)
         if fused:
             # mixed model: per-tensor means from the fused launch's scalar with n_batches = 1

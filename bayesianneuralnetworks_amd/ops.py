@@ -714,7 +714,9 @@ def _kl_descs(mus, rhos, priors):
 
 
 class _KLNormal(torch.autograd.Function):
-    """Returns out (T + 1): per-tensor KL SUMS then the KLDivergence scalar (loss.py:16-38)."""
+    """Returns (out, scalar): out (T + 1) = per-tensor KL SUMS then the KLDivergence scalar (loss.py:16-38); scalar = the
+    0-d view out[T] made inside forward, so that a loss built on it back-propagates straight into this node (selecting
+    out[T] outside costs the backward a zero-fill and a copy launch)."""
 
     @staticmethod
     def forward(ctx, n_batches, priors, out, *params):
@@ -737,16 +739,23 @@ class _KLNormal(torch.autograd.Function):
                                           stream_ptr(dev)), "bnn_kl_forward")
         ctx.save_for_backward(*params)
         ctx.n_batches, ctx.priors, ctx.T = float(n_batches), priors, T
-        return out
+        ctx.set_materialize_grads(False)
+        return out, out[T]
 
     @staticmethod
-    def backward(ctx, g_out):
-        # Only the scalar out[T] is differentiable here (the per-tensor sums are reported
-        # for diagnostics / the sharded all-reduce and carry no gradient).
+    def backward(ctx, g_out, g_scalar):
+        # Only the scalar is differentiable here -- as the second output, or as out[T] of the first (the per-tensor sums
+        # are reported for diagnostics / the sharded all-reduce and carry no gradient).
         params = ctx.saved_tensors
         T = ctx.T
         mus, rhos = params[:T], params[T:]
-        up = g_out[T:T + 1].contiguous()
+        if g_out is None and g_scalar is None:
+            return (None, None, None) + (None,) * (2 * T)
+        up = g_scalar.reshape(1) if g_scalar is not None else None
+        if g_out is not None:
+            up2 = g_out[T:T + 1].contiguous()
+            up = up2 if up is None else up + up2
+        up = up.contiguous()
         if FUSE_KL_GRADIENT and all(m.is_leaf and r.is_leaf for m, r in zip(mus, rhos)) and \
                 not any((m.device.index, m.data_ptr()) in _kl_pending for m in mus):       # (two KL terms on one tensor: no parking)
             # park the gradient for the layers' weight-gradient launches (see _kl_pending above)
@@ -769,7 +778,14 @@ def kl_normal(mus, rhos, priors, n_batches=1.0, out=None):
     then the KLDivergence scalar.  `out` (optional, T + 1 floats) receives the result in place."""
     mus = [m.contiguous() for m in mus]
     rhos = [r.contiguous() for r in rhos]
-    return _KLNormal.apply(n_batches, tuple(priors), out, *mus, *rhos)
+    return _KLNormal.apply(n_batches, tuple(priors), out, *mus, *rhos)[0]
+
+
+def kl_normal_scalar(mus, rhos, priors, n_batches=1.0):
+    """The KLDivergence scalar of kl_normal as a 0-d tensor (differentiable; what KLDivergence.forward returns)."""
+    mus = [m.contiguous() for m in mus]
+    rhos = [r.contiguous() for r in rhos]
+    return _KLNormal.apply(n_batches, tuple(priors), None, *mus, *rhos)[1]
 
 
 class KlDeferred:
