@@ -106,6 +106,7 @@ SIGNATURES = {
     "bnn_colsum": (_int, [_p, _i64, _i64, _p, _i64, _i64, _int, _int, _p]),
     "bnn_relu_backward": (_int, [_p, _p, _p, _i64, _int, _p]),
     "bnn_adam_step": (_int, [ctypes.POINTER(AdamTensor), _int, _f, _f, _f, _f, _f, _p, _p]),
+    "bnn_adam_step_advance": (_int, [ctypes.POINTER(AdamTensor), _int, _f, _f, _f, _f, _f, _p, _p, ctypes.c_uint32, _p]),
     "bnn_xent_workspace_bytes": (_i64, [_i64]),
     "bnn_softmax_xent": (_int, [_p, _p, _i64, _int, _p, _p, _p, _p]),
     "bnn_conv2d_im2col": (_int, [_p, _i64, ctypes.POINTER(Conv2dShape), _int, _p, _int, _p]),

@@ -72,7 +72,13 @@ __global__ __launch_bounds__(kAdamThreads) void k_adam(AdamLaunch L, const float
     }
 }
 
-__global__ void k_adam_step_bump(float *step) { step[0] += 1.0f; }
+// (+ the device epoch of the eps generator, when the optimizer step is also the end of the training step: one 1-thread
+// launch instead of two -- each costs ~4 us)
+__global__ void k_adam_step_bump(float *step, uint32_t *epoch_dev, uint32_t inc)
+{
+    step[0] += 1.0f;
+    if (epoch_dev) epoch_dev[0] += inc;
+}
 
 // Mean cross-entropy over R rows of C <= 64 logits each (CrossEntropyLoss, reduction = 'mean'):
 //   loss = mean_r (logsumexp(x_r) - x_r[y_r]);   gx_r = (softmax(x_r) - onehot(y_r)) / R
@@ -125,6 +131,12 @@ extern "C" {
 int bnn_adam_step(const bnn_adam_tensor_t *tensors, int ntensors, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float *step, void *stream)
 {
+    return bnn_adam_step_advance(tensors, ntensors, lr, beta1, beta2, eps, weight_decay, step, nullptr, 0, stream);
+}
+
+int bnn_adam_step_advance(const bnn_adam_tensor_t *tensors, int ntensors, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, float *step, uint32_t *advance_epoch, uint32_t advance_inc, void *stream)
+{
     const char *who = "bnn_adam_step";
     if (!tensors || !step) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (ntensors < 1) { set_error("%s: ntensors < 1", who); return BNN_E_SHAPE; }
@@ -153,7 +165,7 @@ int bnn_adam_step(const bnn_adam_tensor_t *tensors, int ntensors, float lr, floa
         const int rc = check_launch(who);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_adam_step_bump, dim3(1), dim3(1), 0, st, step);
+    hipLaunchKernelGGL(k_adam_step_bump, dim3(1), dim3(1), 0, st, step, advance_epoch, advance_inc);
     return check_launch(who);
 }
 

@@ -17,16 +17,19 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, advance=None):
+        """advance (optional, a device epoch cell of _rng.EpsGenerator.epoch_dev): bumped by one in the step's last launch
+        -- the fresh-noise step of a captured training step without a launch of its own (last parameter group only)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        for group in self.param_groups:
+        groups = [g for g in self.param_groups if any(p.grad is not None for p in g["params"])]
+        if advance is not None and not groups:
+            check(lib.bnn_rng_advance(ptr(advance), 1, stream_ptr(advance.device)), "bnn_rng_advance")
+        for gi, group in enumerate(groups):
             ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
-                continue
             dev = ps[0].device
             arr = (AdamTensor * len(ps))()
             for i, p in enumerate(ps):
@@ -43,7 +46,8 @@ class Adam(torch.optim.Optimizer):
                 arr[i].m, arr[i].v, arr[i].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
             if "step" not in group:
                 group["step"] = torch.zeros(1, dtype=torch.float32, device=dev)
-            check(lib.bnn_adam_step(arr, len(ps), float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
-                                    float(group["eps"]), float(group["weight_decay"]), ptr(group["step"]), stream_ptr(dev)),
-                  "bnn_adam_step")
+            adv = advance if (advance is not None and gi == len(groups) - 1) else None
+            check(lib.bnn_adam_step_advance(arr, len(ps), float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
+                                            float(group["eps"]), float(group["weight_decay"]), ptr(group["step"]),
+                                            ptr(adv) if adv is not None else None, 1, stream_ptr(dev)), "bnn_adam_step")
         return loss

@@ -255,16 +255,15 @@ class TrainStep:
             self.opt.zero_grad(set_to_none=True)
             with torch.cuda.graph(g):
                 self._body()
-                self.opt.step()
-                # fresh noise on every replay, bumped AFTER the backward re-created this step's draws
-                _lib.check(lib.bnn_rng_advance(_lib.ptr(cell), 1, _lib.stream_ptr(dev)), "bnn_rng_advance")
+                # fresh noise on every replay, bumped AFTER the backward re-created this step's draws: in Adam's last launch
+                self.opt.step(advance=cell)
             self.graph = g
 
     def _body(self):
         ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)      # (S, B, 10)
         loss = self.ops.cross_entropy(ys.reshape(SAMPLES * BATCH, -1), self.target) + self.kld(self.net)
         loss.backward()
-        self.loss.copy_(loss.detach())
+        self.loss = loss.detach()           # (no copy launch: under a graph this is the capture's own tensor, rewritten by every replay)
 
     def _eager(self):
         if self.red is not None:

@@ -359,6 +359,12 @@ typedef struct bnn_adam_tensor {
 } bnn_adam_tensor_t;
 int bnn_adam_step(const bnn_adam_tensor_t *tensors, int ntensors, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float *step, void *stream);
+/* The same step, and advance_epoch[0] += advance_inc (may be NULL) in its last launch: the optimizer step is the end of
+ * a training step (every draw of the step, forward and backward, has been consumed by then), so the fresh-noise bump of a
+ * captured step needs no launch of its own (bnn_rng_advance). */
+int bnn_adam_step_advance(const bnn_adam_tensor_t *tensors, int ntensors, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, float *step, uint32_t *advance_epoch,
+                          uint32_t advance_inc, void *stream);
 /* replaces  torch.nn.CrossEntropyLoss()(pred, y)   examples/MNIST/train.py:39,59-61  (reduction 'mean'):
  *   loss[0] = mean_r (logsumexp(x_r) - x_r[y_r]);  g_logits (may be NULL) = (softmax(x_r) - onehot(y_r)) / rows.
  * logits (rows, classes) fp32 row-major, target int64; workspace: bnn_xent_workspace_bytes(rows). */
