@@ -504,7 +504,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
         lds_wait_ge(&full[ch % NB], NW * (ch / NB + 1));                // chunk ch drawn by every wave
         stamp(4);
 #ifndef BNN_NO_PIPE
-        if constexpr (!F32 && ABF && CH == 2 && S == 3) {          // (CH = 8, the head: measured, no gain)
+        if constexpr (!F32 && ABF && CH == 2 && S >= 3) {          // (CH = 8, the head: measured, no gain)
             // The k-steps of a chunk, software-pipelined one deep: the fragments of step j+1 are requested around the MFMAs
             // of step j (a step was wait -> ds_read_b128s -> MFMAs, the LDS latency exposed at every step; the 10-wide head
             // has ONE MFMA per step).  The stage refill D(kt+3) moves behind the MFMAs of step j: it overwrites the stage
@@ -524,14 +524,15 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                 for (int a = 0; a < TM; ++a) afr[j & 1][a] = As[bpos<false>(a * 16 + fi, fq)];
             };
             dma_A((kt0 + S - 1) % S, kt0 + S - 1);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW + LPU) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 1) * PW + LPU) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             load_frags(0);
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 if (j + 1 < CH) {
-                    if (j + 1 <= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW + LPU) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+                    // S-stage ring: D(kt0+j+1) is followed by D(kt0+j+2) .. D(kt0+j+S-1), and by R while j + 1 <= S - 2
+                    if (j + 1 <= S - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 2) * PW + LPU) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 2) * PW) : "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     load_frags(j + 1);
                     // (no scheduling barrier here: hipcc sinks part of these reads below step j's first MFMAs to reuse
@@ -837,6 +838,7 @@ static void select_pc(GemmParams &p, hipStream_t st)
                 if (splitk_ok(p, 64, 16, 4)) launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP, true, 4>(p, st);
                 else launch_sym<8, 16, 16, 8, 3, 4, BMODE, CP, true>(p, st);
             } else {
+                // (a 4-stage A ring, one more k-step of DMA lead: measured equal, 0.0930 vs 0.0930 ms)
                 launch_sym<16, 32, 48, 2, 3, 4, BMODE, CP, true>(p, st);
             }
             return;
