@@ -16,7 +16,7 @@ F32, BF16 = 0, 1
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
 FLAG_RELU = 1
 FLAG_X_BF16 = 2
-E_ALIGN, E_UNSUPPORTED = -4, -6          # BNN_E_ALIGN, BNN_E_UNSUPPORTED (include/bnn_hip.h)
+E_ALIGN, E_UNSUPPORTED, E_DEVICE = -4, -6, -7     # BNN_E_ALIGN, BNN_E_UNSUPPORTED, BNN_E_DEVICE (include/bnn_hip.h)
 FLAG_Y_BF16 = 4
 
 
@@ -76,6 +76,7 @@ SIGNATURES = {
     "bnn_last_error": (ctypes.c_char_p, []),
     "bnn_launch_count": (ctypes.c_uint64, []),
     "bnn_set_workspace": (_int, [_int, _p, _i64]),
+    "bnn_check_device": (_int, [_int, _p]),
     "bnn_sample_affine_eps": (_int, [_p, _p, _p, _p, _i64, _int, _p]),
     "bnn_sample_affine_philox": (_int, [_p, _p, _p, _i64, _int, _i64, _int, _rngp, _p]),
     "bnn_eps_philox": (_int, [_p, _i64, _int, _i64, _rngp, _p]),
@@ -145,8 +146,36 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _DeviceGuarded(lib)
+    return _lib
+
+
+class _StreamPtr(ctypes.c_void_p):
+    """hipStream_t of torch's current stream on `device_index` (what stream_ptr returns)."""
+    device_index = None
+
+
+class _DeviceGuarded:
+    """The loaded library; a call whose stream argument belongs to another device than the current one runs with
+    that device current (kernels launch on -- and use the registered workspace of -- the current device, so a model
+    on cuda:1 must not launch while cuda:0 is current).  The common case (same device) costs one comparison."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*args):
+            st = args[-1] if args else None
+            if isinstance(st, _StreamPtr) and st.device_index is not None and st.device_index != torch.cuda.current_device():
+                with torch.cuda.device(st.device_index):
+                    return fn(*args)
+            return fn(*args)
+
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
 
 
 _workspaces = {}
@@ -170,7 +199,20 @@ def check(rc, what):
 
 
 def stream_ptr(device=None):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """torch's current stream on `device` as the C-ABI's `stream` argument (it remembers the device: see _DeviceGuarded)."""
+    sp = _StreamPtr(torch.cuda.current_stream(device).cuda_stream)
+    if device is not None:
+        d = torch.device(device)
+        sp.device_index = d.index if d.index is not None else torch.cuda.current_device()
+    return sp
+
+
+def check_device(device=None):
+    """Synchronise `device`'s current stream and raise BnnHipError if a kernel reported an internal error since the
+    last check (the device error word, include/bnn_hip.h: bnn_check_device).  A check point, not a per-launch call."""
+    d = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    check(load().bnn_check_device(idx, stream_ptr(torch.device("cuda", idx))), "bnn_check_device")
 
 
 def ptr(t):

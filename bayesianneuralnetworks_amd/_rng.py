@@ -15,10 +15,15 @@ _lock = threading.Lock()
 
 
 def new_stream_id():
-    """A tensor-stream id (< 65536), handed out in construction order so that every rank
-    of a multi-GPU run that builds the same model gets the same ids."""
+    """A tensor-stream id (1 .. 65535: 16 bits of the Philox counter), handed out in construction order so
+    that every rank of a multi-GPU run that builds the same model gets the same ids.  Ids are never reused:
+    a wrapped id would make two tensors draw identical eps, so the 65 536th request raises."""
     with _lock:
-        return next(_stream_ids) & 0xFFFF
+        i = next(_stream_ids)
+    if i > 0xFFFF:
+        raise RuntimeError("eps stream ids exhausted: more than 65535 posterior tensors were created in this process "
+                           "(the stream field of the Philox counter is 16 bits wide)")
+    return i
 
 
 class EpsGenerator:

@@ -372,17 +372,19 @@ static int dispatch(GemmParams &p, bool sampled, int compute, hipStream_t st, co
     return check_launch(who);
 }
 
-// Per-device scratch registered by the host (bnn_set_workspace): [tickets: 64 KiB][slabs: rest].
+// Per-device scratch registered by the host (bnn_set_workspace): [error word + reserved: 64 KiB][slabs: rest].
 static void *g_ws[64];
 static int64_t g_ws_bytes[64];
 constexpr int64_t kTicketBytes = 64 * 1024;
 
+// The workspace of the device the launch goes to.  Every launch of this library goes to the CURRENT device (the host
+// side makes the operands' device current around each call: _lib._StreamPtr), so that is the device whose scratch the
+// kernel may touch.
 void fill_workspace(GemmParams &p)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_ws[dev] || g_ws_bytes[dev] <= kTicketBytes) return;
-    p.ws_tickets = reinterpret_cast<int *>(g_ws[dev]);
-    p.ws_max_tickets = kTicketBytes / 4;
+    p.dev_err = reinterpret_cast<unsigned *>(g_ws[dev]);
     p.ws_slabs = reinterpret_cast<float *>(reinterpret_cast<char *>(g_ws[dev]) + kTicketBytes);
     p.ws_slab_bytes = g_ws_bytes[dev] - kTicketBytes;
 }
@@ -709,6 +711,28 @@ static int conv_common(const float *x, int64_t x_sample_stride, const float *w, 
 using namespace bnn;
 
 extern "C" {
+
+int bnn_check_device(int device, void *stream)
+{
+    if (device < 0 || device >= 64) { set_error("bnn_check_device: device out of range"); return BNN_E_RANGE; }
+    if (!g_ws[device]) return BNN_OK;                       // no workspace registered: kernels had no word to set
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device && hipSetDevice(device) != hipSuccess) { set_error("bnn_check_device: cannot select device %d", device); return BNN_E_RANGE; }
+    unsigned word = 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(&word, g_ws[device], sizeof(word), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && word) e = hipMemsetAsync(g_ws[device], 0, sizeof(word), st);
+    if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+    if (e != hipSuccess) { set_error("bnn_check_device: %s", hipGetErrorString(e)); return (int)e; }
+    if (word) {
+        set_error("device error word 0x%x:%s", word,
+                  (word & kDevErrHandoffTimeout) ? " a hand-off wait of the fused linear kernel timed out (its tile was not stored)" : "");
+        return BNN_E_DEVICE;
+    }
+    return BNN_OK;
+}
 
 int bnn_set_workspace(int device, void *ptr, int64_t bytes)
 {

@@ -12,6 +12,8 @@ enum { B_PLAIN = 0, B_SAMPLED = 1, B_SAMPLED_T = 2 };
 // internal epilogue flag (not part of the C-ABI flags): row m = (image, pixel) -> y[image][n][pixel], i.e. the
 // conv output in NCHW; OH * OW pixels per image, O channels
 constexpr int kFlagStoreNCHW = 1 << 16;
+// bits of the sticky device error word (word 0 of the registered workspace)
+constexpr unsigned kDevErrHandoffTimeout = 1u;   // a bounded LDS hand-off wait of the fused linear kernel gave up
 // internal compute mode of the fast linear kernel (not a C-ABI value): fp32-accurate results on the bf16 MFMA
 constexpr int kComputeBf16x3 = 2;
 
@@ -45,10 +47,9 @@ struct GemmParams {
     int32_t flags;
     int32_t vecA, vecB;         // 16-B loads legal
     RngDev rng_w, rng_b;
-    // split-K scratch (bnn_set_workspace): tickets (never reset; last arriver = ticket % KS == KS-1)
-    int *ws_tickets;
-    int64_t ws_max_tickets;
-    float *ws_slabs;
+    // registered scratch (bnn_set_workspace): [device error word + reserved: 64 KiB][slabs: rest]
+    unsigned *dev_err;          // sticky device error word (kDevErr* bits; bnn_check_device reads and clears it), or NULL
+    float *ws_slabs;            // fixed-order partial sums of the backward kernels' sample / row splits
     int64_t ws_slab_bytes;
     // KL first pass carried by this launch (bnn_linear_forward_sampled_kl): workgroups >= gemm_grid run kl_piggy_block
     KlPiggy kl;

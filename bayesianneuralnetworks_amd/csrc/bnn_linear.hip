@@ -53,14 +53,20 @@ __device__ __forceinline__ int lds_load(int *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Poll an LDS counter until it reaches `target` (bounded: a protocol bug must not hang the GPU).
-__device__ __forceinline__ void lds_wait_ge(int *p, int target)
+// Poll an LDS counter until it reaches `target`.  Bounded: a protocol bug must not hang the GPU -- and must not
+// turn into wrong numbers either: on a timeout the wave sets the sticky device error word (word 0 of the registered
+// workspace, read and cleared by bnn_check_device) and the caller skips its stores.  Returns false on a timeout.
+__device__ __forceinline__ bool lds_wait_ge(int *p, int target, unsigned *err)
 {
-    for (int spin = 0; spin < (1 << 24); ++spin) {
-        if (lds_load(p) >= target) break;
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (lds_load(p) >= target) { ok = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (!ok && err && (threadIdx.x & 63) == 0)
+        __hip_atomic_fetch_or(err, kDevErrHandoffTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
 }
 
 // Symmetric pipeline: every wave draws its share of chunk ch+1, then consumes chunk ch for its own
@@ -75,11 +81,9 @@ __device__ __forceinline__ void lds_wait_ge(int *p, int target)
 // reduction runs over the weight's ROWS, so a 4-draw unit (one Philox block = 4 consecutive columns of
 // one row) lands in four LDS rows at one reduction position (4 scalar LDS writes instead of one
 // vector write); p.N = columns of W (outputs here), p.K = rows of W (reduction), row length p.N.
-// KS > 1: split-K -- KS workgroups share one output tile, each reduces a contiguous range of
-// k-chunks into an fp32 slab of the registered workspace; the last arriver (agent-scope release /
-// acquire around one ticket per tile) adds the KS slabs in a FIXED order, so results stay bitwise
-// reproducible.  Used for N <= 16 heads, where one tile's K loop is a long serial chain.
-template <int NW, int RW, int BN, int CH, int S, int NB, int B_MODE, int COMPUTE, bool ABF = false, bool STAMPS = false, int KS = 1>
+// (A split-K variant for the N <= 16 head existed in round 1 behind BNN_SPLITK; it faulted once on the box at 64 tiles x 4
+// splits, the cause was not found from the evidence in hand, and it bought 3 % of the step: removed in round 2.)
+template <int NW, int RW, int BN, int CH, int S, int NB, int B_MODE, int COMPUTE, bool ABF = false, bool STAMPS = false>
 __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
 {
     constexpr bool F32 = (COMPUTE == BNN_COMPUTE_F32);
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     // Narrow-layer (N <= 16) forward: its 32 workgroups leave most of the chip idle, so the launch can carry the
     // first pass of the model's KL as extra workgroups (a launch of its own costs >= 4 us).  They use the first 256
     // threads; the other waves retire at once (a retired wave no longer counts at the barrier).
-    constexpr bool CARRIES_KL = (B_MODE == B_SAMPLED && BN == 16 && KS == 1 && !STAMPS);
+    constexpr bool CARRIES_KL = (B_MODE == B_SAMPLED && BN == 16 && !STAMPS);
     if constexpr (CARRIES_KL) {
         if (p.kl.nblocks > 0 && (int)blockIdx.x >= p.gemm_grid) {
             if (threadIdx.x < 256) kl_piggy_block(p.kl, (int)blockIdx.x - p.gemm_grid);
@@ -146,13 +150,12 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     };
 
     // ---- block decode
-    const int ks = (KS > 1) ? (int)(blockIdx.x % KS) : 0;
-    const int L = (KS > 1) ? (int)(blockIdx.x / KS) : (int)blockIdx.x;
+    const int L = (int)blockIdx.x;
     int s, panel, mt;
     {
         const int per_s = p.ntn * p.ntm;
         int rem;
-        if (KS == 1 && p.xcd_a > 0) {
+        if (p.xcd_a > 0) {
             // 2-D XCD map: XCD (blockIdx % 8) = (sample group, panel group).  One XCD's L2 then holds 1/xb of
             // mu / rho and 1/xa of the activations instead of ALL of mu / rho (sample -> XCD): fabric traffic
             // of layer 2 falls from 8 x 11.5 + 9.8 MB to 8 x (2.9 + 4.9) MB.  The grid is padded to the largest
@@ -185,10 +188,9 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     const int kmax = p.K - 4;
     const int nk_all = (p.K + 31) / 32;                 // 32-wide k-steps
     const int nch_all = (nk_all + CH - 1) / CH;         // chunks (steps past K multiply exact zeros)
-    const int c_lo = (KS > 1) ? ks * nch_all / KS : 0;  // this workgroup's chunk range
-    const int c_hi = (KS > 1) ? (ks + 1) * nch_all / KS : nch_all;
-    const int nch = c_hi - c_lo;
-    const int k_lo = c_lo * (32 * CH);                  // absolute k of local chunk 0
+    const int nch = nch_all;
+    constexpr int k_lo = 0;
+    bool handoff_ok = true;                             // false after a bounded hand-off wait gave up
 
     if (tid < 2 * NB) full[tid] = 0;
     // the panel's BN bias values, drawn ONCE per workgroup (every wave needs all of them in its epilogue; per
@@ -495,13 +497,13 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
         // least one iteration ago when NB > LA + 1 (slack instead of a per-chunk rendezvous)
         const int cd = ch + LA;
         if (cd < nch) {
-            if (cd >= NB) lds_wait_ge(&freec[cd % NB], NW * (cd / NB));  // its buffer is free again
+            if (cd >= NB) handoff_ok &= lds_wait_ge(&freec[cd % NB], NW * (cd / NB), p.dev_err);  // its buffer is free again
             stamp(2);
             draw_unit(cur, cd);
             publish(cd);
         }
         stamp(3);
-        lds_wait_ge(&full[ch % NB], NW * (ch / NB + 1));                // chunk ch drawn by every wave
+        handoff_ok &= lds_wait_ge(&full[ch % NB], NW * (ch / NB + 1), p.dev_err);   // chunk ch drawn by every wave
         stamp(4);
 #ifndef BNN_NO_PIPE
         if constexpr (!F32 && ABF && CH == 2 && S >= 3) {          // (CH = 8, the head: measured, no gain)
@@ -616,52 +618,9 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(12);                                                      // loop done
 
-    if constexpr (KS > 1) {
-        // ---- split-K: publish this workgroup's partial tile, last arriver reduces (fixed order)
-        const int tile_id = (s * p.ntm + mt) * p.ntn + panel;
-        if (tile_id < 0 || tile_id >= p.ws_max_tickets ||
-            (int64_t)(tile_id + 1) * KS * (BM * BN) * 4 > p.ws_slab_bytes) {
-            // cannot happen when the host sized the workspace (splitk_ok); never index outside it
-            if (tid == 0) p.Y[0] = __int_as_float(0x7fc00000 | (tile_id & 0xffff));
-            return;
-        }
-        float *slab0 = p.ws_slabs + (int64_t)tile_id * KS * (BM * BN);
-        float *mine = slab0 + (int64_t)ks * (BM * BN);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    mine[(wave * RW + a * 16 + fq * 4 + r) * BN + b * 16 + fi] = acc[a][b][r];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave
-        __syncthreads();
-        int *lastflag = full;                                            // LDS word, free after the loop
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int old = __hip_atomic_fetch_add(p.ws_tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = ((old % KS) == KS - 1);                     // tickets are never reset
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            *lastflag = last;
-        }
-        __syncthreads();
-        if (*lastflag == 0) return;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = (wave * RW + a * 16 + fq * 4 + r) * BN + b * 16 + fi;
-                    float v = 0.f;
-                    for (int q = 0; q < KS; ++q) v += slab0[(int64_t)q * (BM * BN) + idx];
-                    acc[a][b][r] = v;
-                }
-    }
+    // a hand-off wait that gave up has consumed an undrawn chunk or drawn into a busy buffer: the device error word is
+    // set (bnn_check_device reports it) and this wave's results are not stored
+    if (!__builtin_amdgcn_readfirstlane((int)handoff_ok)) return;
 
     // ---- epilogue: bias (drawn at kernel entry), activation, store
     const bool sampled_bias = (p.mu_b != nullptr);
@@ -751,15 +710,15 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     stamp(13);                                                      // epilogue stores retired
 }
 
-template <int NW, int RW, int BN, int CH, int S, int NB, int BMODE, int CP, bool ABF = false, int KS = 1>
+template <int NW, int RW, int BN, int CH, int S, int NB, int BMODE, int CP, bool ABF = false>
 static void launch_sym(GemmParams &p, hipStream_t st)
 {
     constexpr int BM = NW * RW;
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = (p.N + BN - 1) / BN;
-    int64_t grid = (int64_t)p.ntn * p.ntm * p.S * KS;
+    int64_t grid = (int64_t)p.ntn * p.ntm * p.S;
     p.xcd_a = 0;
-    if (KS == 1 && p.S % 8 == 0 && p.ntn >= 8) {
+    if (p.S % 8 == 0 && p.ntn >= 8) {
         // choose the XCD grid (xa sample groups x 8/xa panel groups) with the least L2 fill per XCD:
         // weights / xb + activations / xa (a shared input counts once whatever xa is)
         static const int force = [] { const char *e = getenv("BNN_XCD_A"); return e ? atoi(e) : -1; }();
@@ -781,10 +740,6 @@ static void launch_sym(GemmParams &p, hipStream_t st)
             grid = (int64_t)8 * (p.S / best) * ppg * p.ntm;
         }
     }
-    if constexpr (KS > 1) {
-        hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, ABF, false, KS>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
-        return;
-    }
     if constexpr (BMODE == B_SAMPLED && CP == BNN_COMPUTE_BF16 && BN > 16) {
         // diagnostic build with in-kernel stamps (tools/stamps.py): BNN_STAMPS=<device pointer>
         static unsigned long long *dbg = [] { const char *e = getenv("BNN_STAMPS"); return e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }();
@@ -795,7 +750,7 @@ static void launch_sym(GemmParams &p, hipStream_t st)
             return;
         }
     }
-    if constexpr (BMODE == B_SAMPLED && BN == 16 && KS == 1 && NW >= 4) {
+    if constexpr (BMODE == B_SAMPLED && BN == 16 && NW >= 4) {
         if (p.kl.nblocks > 0 && !p.kl.taken && grid + p.kl.nblocks < 0x7FFFFFFF) {
             p.gemm_grid = (int32_t)grid;
             grid += p.kl.nblocks;
@@ -803,19 +758,6 @@ static void launch_sym(GemmParams &p, hipStream_t st)
         }
     }
     hipLaunchKernelGGL((k_linear_sym<NW, RW, BN, CH, S, NB, BMODE, CP, ABF>), dim3((unsigned)grid), dim3(NW * 64), 0, st, p);
-}
-
-// split-K needs the registered workspace (bnn_set_workspace) to hold tickets + slabs, and a K loop
-// long enough to be worth splitting.
-static bool splitk_ok(const GemmParams &p, int bm, int bn, int ks)
-{
-    // OPT-IN (BNN_SPLITK=1) in round 1: the split-K head passes parity at <= 8 tiles but faulted
-    // (memory aperture violation) at 64 tiles x 4 splits on the box; until that is understood the
-    // unsplit kernel is the only one dispatched by default.
-    static const bool on = [] { const char *e = getenv("BNN_SPLITK"); return e && e[0] == '1'; }();
-    if (!on || !p.ws_slabs || !p.ws_tickets || p.K < 256) return false;
-    const int64_t tiles = (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.S;
-    return tiles <= p.ws_max_tickets && tiles * ks * bm * bn * 4 <= p.ws_slab_bytes;
 }
 
 // BNN_F32_MFMA=native: the fp32 mode on v_mfma_f32_16x16x4_f32 (exact fp32 products); default: bf16x3
@@ -835,8 +777,7 @@ static void select_pc(GemmParams &p, hipStream_t st)
             if (p.N <= 16) {
                 // head: 128 x 16 tiles, 256-k chunks (5 hand-offs instead of 19 at K = 1200; measured
                 // against 64 x 16 / 64-k chunks: step 0.1203 -> 0.1168 ms)
-                if (splitk_ok(p, 64, 16, 4)) launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP, true, 4>(p, st);
-                else launch_sym<8, 16, 16, 8, 3, 4, BMODE, CP, true>(p, st);
+                launch_sym<8, 16, 16, 8, 3, 4, BMODE, CP, true>(p, st);
             } else {
                 // (a 4-stage A ring, one more k-step of DMA lead: measured equal, 0.0930 vs 0.0930 ms)
                 launch_sym<16, 32, 48, 2, 3, 4, BMODE, CP, true>(p, st);
@@ -845,9 +786,8 @@ static void select_pc(GemmParams &p, hipStream_t st)
         }
     }
     if (p.N <= 16) {
-        if (splitk_ok(p, 64, 16, 4)) launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP, false, 4>(p, st);   // 64 x 16 tiles, split-K
         // fp32 mode: the bf16 head's shape (128 x 16 tiles, 256-k chunks) on bf16x3 splits (fp32 step 0.1927 -> 0.1901 ms)
-        else if (CP == BNN_COMPUTE_F32 && f32x3_enabled()) launch_sym<8, 16, 16, 8, 3, 4, BMODE, kComputeBf16x3>(p, st);
+        if (CP == BNN_COMPUTE_F32 && f32x3_enabled()) launch_sym<8, 16, 16, 8, 3, 4, BMODE, kComputeBf16x3>(p, st);
         else launch_sym<4, 16, 16, 2, 3, 4, BMODE, CP>(p, st);
     } else if (CP == BNN_COMPUTE_F32 && f32x3_enabled() && tile == 0) {
         // fp32 results from the bf16 MFMA (kComputeBf16x3): 256 x 80 tiles, 64-k chunks, 2 chunk buffers (three B images)

@@ -22,7 +22,7 @@ def get_compute():
 def fuse_kl_gradient(enable=True):
     """Opt-in for training loops of the form `(likelihood + KLDivergence(...)(model)).backward()` (the reference's
     train.py:57-64): KLDivergence's backward then leaves its gradient to the layers' weight-gradient launches,
-    which add the closed form in their final store (ops._kl_pending) -- no separate KL pass, no accumulation add
+    which add the closed form in their final store (ops._tls.kl_pending) -- no separate KL pass, no accumulation add
     per parameter.  Leave it off when the KL gradient is taken with torch.autograd.grad(): the parked gradient
     reaches `.grad`, not the returned tuple."""
     from .. import ops

@@ -23,6 +23,22 @@ class BayesianModule(Module):
         self.in_channels = in_channels
         self.out_channels = out_channels
 
+    def kl_divergence(self, number_of_batches=1):
+        """Convenience BASELINE.json's north_star names (the reference has only the module form, loss.py:11-38):
+        `KLDivergence(number_of_batches)` over this layer's own weight / bias posteriors."""
+        from .loss import KLDivergence
+        return KLDivergence(number_of_batches)(_Single(self))
+
+
+class _Single:
+    """A one-layer 'model' for KLDivergence.forward: traverse(fn) visits just that layer."""
+
+    def __init__(self, layer):
+        self.layer = layer
+
+    def traverse(self, fn, *args, **kwargs):
+        return traverse(self.layer, fn, *args, **kwargs)
+
 
 class BayesianNetworkModule(Module):
     """container.py:17-37.  Subclasses implement `_forward`."""
@@ -41,6 +57,11 @@ class BayesianNetworkModule(Module):
 
     def traverse(self, fn, *args, **kwargs):
         return traverse(self, fn, *args, **kwargs)
+
+    def kl_divergence(self, number_of_batches=1):
+        """`KLDivergence(number_of_batches)(self)` (loss.py:30-38) -- the `.kl_divergence()` BASELINE.json's north_star names."""
+        from .loss import KLDivergence
+        return KLDivergence(number_of_batches)(self)
 
     def forward(self, x, samples=None, *args, **kwargs):
         if samples is None:

@@ -8,6 +8,7 @@ torch.bmm / torch's conv backward on the GPU (library GEMMs on already-drawn wei
 Every function here requires CUDA (HIP) tensors and raises BnnHipError otherwise.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -151,8 +152,7 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
         check(_lib.load().bnn_linear_forward(ptr(x2), x_sample_stride, K, ptr(w), N * K, ptr(b), N, ptr(y), M * N, N, M, N, K, S,
                                               compute, flags, stream_ptr(x2.device)), "bnn_linear_forward")
         return y
-    global _kl_carry
-    h = _kl_carry
+    h = _tls.kl_carry
     if h is not None and N <= 16 and not h.launched and h.out.device == x2.device:
         # a narrow layer: its launch carries the first pass of the KL begun with kl_normal_begin(carry=True)
         check(_lib.load().bnn_linear_forward_sampled_kl(
@@ -160,7 +160,7 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
             ptr(y), M * N, N, M, N, K, S, ctypes.byref(rw), ctypes.byref(rb) if rb is not None else None,
             compute, flags, h.arr, h.T, ptr(h.ws), stream_ptr(x2.device)), "bnn_linear_forward_sampled_kl")
         h.launched = True
-        _kl_carry = None
+        _tls.kl_carry = None
         return y
     check(_lib.load().bnn_linear_forward_sampled(
         ptr(x2), x_sample_stride, K, ptr(mu_w), ptr(rho_w), ptr(mu_b), ptr(rho_b),
@@ -169,8 +169,18 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
     return y
 
 
-# a KlDeferred whose first pass waits for a narrow layer's launch to carry it (kl_normal_begin(carry=True))
-_kl_carry = None
+class _ThreadState(threading.local):
+    """Per-thread hand-over state (two threads driving two models must not see each other's):
+    kl_carry   -- a KlDeferred whose first pass waits for a narrow layer's launch to carry it (kl_normal_begin(carry=True));
+    kl_pending -- KL gradients parked for the layers' weight-gradient launches (FUSE_KL_GRADIENT), keyed by the mean's
+                  storage; a backward pass runs its nodes on the thread that called backward() for its device."""
+
+    def __init__(self):
+        self.kl_carry = None
+        self.kl_pending = {}
+
+
+_tls = _ThreadState()
 # from this many rows per sample on, a sampled linear layer draws its weights once (K1) instead of in the GEMM
 DRAW_ONCE_MIN_ROWS = 2048
 
@@ -189,7 +199,6 @@ def _bf(t):
 # OPT-IN (nn.fuse_kl_gradient(True)): parking returns no gradient from the KL node itself, which is only right when
 # the pass accumulates into .grad (loss.backward()); torch.autograd.grad(kl, params) needs the default path.
 FUSE_KL_GRADIENT = False
-_kl_pending = {}
 
 
 class _KlPending:
@@ -200,7 +209,8 @@ class _KlPending:
 
 
 def _kl_take(mu):
-    return _kl_pending.pop((mu.device.index, mu.data_ptr()), None) if _kl_pending else None
+    pend = _tls.kl_pending
+    return pend.pop((mu.device.index, mu.data_ptr()), None) if pend else None
 
 
 def _kl_fuse_struct(ent_w, ent_b):
@@ -219,10 +229,11 @@ def _kl_fuse_struct(ent_w, ent_b):
 
 def _kl_flush():
     """Engine callback at the end of a backward pass: KL gradients of the tensors no layer picked up."""
-    if not _kl_pending:
+    pend = _tls.kl_pending
+    if not pend:
         return
-    ents = list(_kl_pending.values())
-    _kl_pending.clear()
+    ents = list(pend.values())
+    pend.clear()
     lib = _lib.load()
     for e in ents:
         g_mu, g_rho = torch.empty_like(e.mu), torch.empty_like(e.rho)
@@ -349,7 +360,7 @@ class _SampledLinear(torch.autograd.Function):
             # not applicable here (workspace, alignment): the general kernels below; hand the KL entries back
             for e in (ent_w, ent_b):
                 if e is not None:
-                    _kl_pending[(e.mu.device.index, e.mu.data_ptr())] = e
+                    _tls.kl_pending[(e.mu.device.index, e.mu.data_ptr())] = e
             gx = g_mu_w = g_rho_w = g_mu_b = g_rho_b = None
         if ctx.needs_input_grad[0]:
             # a shared input sums its gradient over the samples: fp32 partials, then one reduction
@@ -757,10 +768,10 @@ class _KLNormal(torch.autograd.Function):
             up = up2 if up is None else up + up2
         up = up.contiguous()
         if FUSE_KL_GRADIENT and all(m.is_leaf and r.is_leaf for m, r in zip(mus, rhos)) and \
-                not any((m.device.index, m.data_ptr()) in _kl_pending for m in mus):       # (two KL terms on one tensor: no parking)
-            # park the gradient for the layers' weight-gradient launches (see _kl_pending above)
+                not any((m.device.index, m.data_ptr()) in _tls.kl_pending for m in mus):   # (two KL terms on one tensor: no parking)
+            # park the gradient for the layers' weight-gradient launches (see _ThreadState above)
             for m, r, pr in zip(mus, rhos, ctx.priors):
-                _kl_pending[(m.device.index, m.data_ptr())] = _KlPending(up, 1.0 / (m.numel() * T * ctx.n_batches), pr, m, r)
+                _tls.kl_pending[(m.device.index, m.data_ptr())] = _KlPending(up, 1.0 / (m.numel() * T * ctx.n_batches), pr, m, r)
             torch.autograd.Variable._execution_engine.queue_callback(_kl_flush)
             return (None, None, None) + (None,) * (2 * T)
         g_mu = [torch.empty_like(m) for m in mus]
@@ -818,8 +829,7 @@ def kl_normal_begin(mus, rhos, priors, n_batches=1.0, out=None, carry=False):
     h.arr, h.T, h.n_batches, h.out, h.ws = _kl_descs(mus, rhos, priors), T, float(n_batches), out, _kl_workspace(dev)
     h.keep, h.done, h.launched = (mus, rhos), False, False
     if carry:
-        global _kl_carry
-        _kl_carry = h
+        _tls.kl_carry = h
         return h
     check(_lib.load().bnn_kl_forward_partial(h.arr, T, ptr(h.ws), stream_ptr(dev)), "bnn_kl_forward_partial")
     h.launched = True
@@ -849,9 +859,8 @@ def mc_mean(y, out=None, scale=None, advance=None, kl=None):
         if kl.done:
             raise BnnHipError("mc_mean: this KlDeferred has already been finished")
         if not kl.launched:                         # no narrow layer took it along
-            global _kl_carry
-            if _kl_carry is kl:
-                _kl_carry = None
+            if _tls.kl_carry is kl:
+                _tls.kl_carry = None
             check(_lib.load().bnn_kl_forward_partial(kl.arr, kl.T, ptr(kl.ws), stream_ptr(y.device)), "bnn_kl_forward_partial")
             kl.launched = True
         check(_lib.load().bnn_mc_sum_kl(ptr(y), n, S, n, sc, ptr(out), 0, adv, 1, kl.arr, kl.T, kl.n_batches,

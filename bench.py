@@ -2,22 +2,29 @@
 """bench.py -- MC-samples/sec of the 784-1200-1200-10 NormalLinear MLP at batch 512
 (BASELINE.json metric; configs[1]: bf16 operands / fp32 accumulate, 8 MC samples per forward).
 
-One step = one stochastic forward of S = 8 MC samples over one synthetic batch of 512
-(all samples of a layer in one fused sampled-GEMM launch), the Gaussian KL once, the
-predictive mean over the samples, and -- for N > 1 -- ONE all-reduce over RCCL of the packed
-[KL sums || sum of predictions] buffer, issued asynchronously so that it runs under the next step.  Weak scaling: every rank runs its own 8 samples
-(sample ids rank*8 .. rank*8+7 of the same posterior), value = N * 8 * steps / time.
+One step = one stochastic forward of the MC samples over one synthetic batch of 512 (all samples of
+a layer in one launch), the Gaussian KL once, the predictive mean over the samples, and -- for
+N > 1 -- ONE all-reduce over RCCL of the packed [KL sums || sum of predictions] buffer, issued
+asynchronously so that it runs under the next step.
 
-Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel, measured live with
-events on the launch stream), `cpu_baseline` (torch-CPU port of the reference, N = 1 only),
-`f32` (same step in the fp32 parity mode), `train` (N = 1: the reference's training-loop
-body, examples/MNIST/train.py:53-65, on the same model -- forward, KL, cross-entropy, HIP
-backward, Adam).  `--mode train` makes the training step the headline value
-(N > 1: MC samples sharded as in the forward, gradients all-reduced in overlapped buckets).
+`--gpus N` with no WORLD_SIZE in the environment starts N rank processes of this script itself
+(before the parent makes any GPU call) and relays rank 0's line.  N > 1 headline = STRONG scaling
+(SURVEY.md 8e / north_star "one sample per GPU"): the S = 8 global MC samples are sharded S / N per
+rank (`distributed.shard_samples`), value = 8 * steps / time; the weak-scaling number (8 samples on
+every rank, value = N * 8 * steps / time) rides along under "weak".
+
+Prints ONE JSON line (rank 0).  Extra keys: `checked` (one more replay of the timed graph compared
+with the CPU oracle on the replay's own draw keys -- a checker, never timed), `roofline` (dominant
+kernel, measured live with events on the launch stream), `roofline_conv_lenet` / `roofline_conv_cifar`
+/ `roofline_wide_f32` (configs[2], [3], [4] layer launches), `cpu_baseline` (torch-CPU port of the
+reference, N = 1 only), `f32` (same step in the fp32 parity mode), `train` (N = 1: the reference's
+training-loop body, examples/MNIST/train.py:53-65, on the same model).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,10 +40,21 @@ P_SCALARS = sum(i * o + o for i, o in zip(DIMS[:-1], DIMS[1:]))          # 2 395
 FLOP_PER_SAMPLE = 2 * BATCH * sum(i * o for i, o in zip(DIMS[:-1], DIMS[1:]))  # 2 450 227 200
 PEAK = {"f32": 157.3, "bf16": 2500.0}       # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-# Fabric-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes
-# (profiles/r01_pmc_layer2_bf16.txt): (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 FETCH_SIZE correction
-# applied.  Not measured live (PMC passes serialise kernels); re-collect with tools/pmc.sh.
-TRAFFIC_PMC = {"bf16": 82.7e6, "f32": None}
+# Fabric-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (PMC passes
+# serialise kernels, so they are not collected live): tools/pmc.sh writes the summary under profiles/ and
+# the number is recorded in this file; a kernel that is not in the file reports traffic = null.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def pmc_traffic(kernel_tag):
+    try:
+        with open(TRAFFIC_FILE) as f:
+            ent = json.load(f).get(kernel_tag)
+    except (OSError, ValueError):
+        return None, None
+    if not ent:
+        return None, None
+    return ent.get("traffic_bytes"), {"file": ent.get("source"), "date": ent.get("date")}
 
 
 def posteriors(seed=0):
@@ -84,18 +102,18 @@ def build_net(dev, post):
 
 
 class Step:
-    """One forward of S samples + KL + predictive mean, optionally captured in a HIP graph.
+    """One forward of `samples` MC samples (global ids sample0 ..) + KL + this rank's share of the predictive
+    mean, optionally captured in a HIP graph.  All launches on one stream (measured: forking the KL onto a
+    second queue costs more in cross-queue dependency latency than it hides).  KL sums and the sum of
+    predictions land directly in the packed buffer that the one collective all-reduces."""
 
-    Launches per step: the multi-tensor KL pair, 3 fused sampled-GEMM kernels (ReLU folded into the
-    first two), and the MC reduction, which also bumps the device epoch -- all on one stream
-    (measured: forking the 13 us of KL onto a second queue costs more in cross-queue dependency
-    latency than it hides).  KL sums and the sum of predictions land directly in the packed buffer
-    that the one collective all-reduces."""
-
-    def __init__(self, net, x, rank, world, use_graph):
+    def __init__(self, net, x, rank, world, use_graph, samples=SAMPLES, sample0=None, total_samples=None):
         from bayesianneuralnetworks_amd import ops, _lib, distributed as bd
         from bayesianneuralnetworks_amd._rng import default_generator
         self.net, self.x, self.rank, self.world = net, x, rank, world
+        self.samples = samples
+        self.sample0 = rank * samples if sample0 is None else sample0
+        self.total = world * samples if total_samples is None else total_samples
         self.ops, self.lib, self._lib = ops, _lib.load(), _lib
         self.gen = default_generator
         self.graph = None
@@ -119,11 +137,15 @@ class Step:
         self.packed = torch.zeros(self.T + 1 + BATCH * DIMS[-1], device=dev)
         self.kl_tmp = torch.zeros(self.Tl + 1, device=dev)
         self.kl_pos = torch.tensor(self.kl_idx, device=dev, dtype=torch.long)
-        self.side = torch.cuda.Stream(dev)
         self.comm = torch.zeros_like(self.packed)
         self.pending = None
         if use_graph:
             self._capture()
+        else:
+            self._body()
+            torch.cuda.synchronize(dev)
+        # the draw keys the captured launches carry (a later Step on the same net re-keys the layers)
+        self.keys = [(L.weight.draw_key, L.bias.draw_key) for L in self.linears]
 
     def _kl(self):
         if self.world == 1:
@@ -144,41 +166,21 @@ class Step:
         return self.ops.kl_normal_begin(self.kl_mu, self.kl_rho, [(0.0, 0.1)] * self.Tl, 1.0, out=out, carry=carry)
 
     def _body(self):
-        """KL placement (BNN_BENCH_KL): 'side' forks it at the start of the step, 'after1' forks it
-        behind the first GEMM (so the GEMM is the graph's root node on the main queue), 'serial'
-        keeps everything on one stream; 'tail' also keeps one stream and runs KL's second pass inside the MC
-        reduction's launch (ops.kl_normal_begin / mc_mean(kl=...)); 'carry' (default) additionally lets the classifier
-        head's launch carry KL's first pass."""
+        """KL placement (BNN_BENCH_KL): 'serial' runs the KL pair first on the one stream; 'tail' runs KL's second
+        pass inside the MC reduction's launch (ops.kl_normal_begin / mc_mean(kl=...)); 'carry' (default) additionally
+        lets the classifier head's launch carry KL's first pass."""
         dev = self.x.device
         mode = os.environ.get("BNN_BENCH_KL", "carry")
         with torch.no_grad():
-            cur = torch.cuda.current_stream(dev)
-            if mode == "side":
-                self.side.wait_stream(cur)
-                with torch.cuda.stream(self.side):
-                    self._kl()
-            elif mode == "serial":
+            if mode == "serial":
                 self._kl()
             kl_h = self._kl_begin(mode == "carry") if mode in ("tail", "carry") else None
-            hook = None
-            if mode == "after1":
-                def hook(_m, _i, _o):
-                    self.side.wait_stream(cur)
-                    with torch.cuda.stream(self.side):
-                        self._kl()
-                h = self.linears[0].register_forward_hook(hook)
-            try:
-                ys = self.net.forward_stacked(self.x, SAMPLES, sample0=self.rank * SAMPLES)   # (S, B, 10)
-            finally:
-                if hook is not None:
-                    h.remove()
+            ys = self.net.forward_stacked(self.x, self.samples, sample0=self.sample0)   # (S, B, 10)
             # fresh noise on every replay: the reduction also bumps the device epoch (last kernel of the step)
-            self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / (SAMPLES * self.world),
+            self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / self.total,
                              advance=self.gen.epoch_dev(dev), kl=kl_h)
             if kl_h is not None and self.world > 1:
                 self._kl_scatter()
-            if mode in ("side", "after1"):
-                cur.wait_stream(self.side)
         return self.packed
 
     def _capture(self):
@@ -218,6 +220,71 @@ class Step:
             self.pending = None
 
 
+# ------------------------------------------------------------------------------------------ checker
+def oracle_check(step, post, x_cpu, mode, rows=64, tap=None):
+    """CHECKER -- never timed, never on the product path.  Replays the step ONCE more and compares it with
+    the CPU oracle (oracle/bnn_oracle.c; pinned to the reference by tests/test_oracle_golden.py) evaluated
+    on the draw keys this replay used: KL scalar, `rows` rows of the predictive mean and (if `tap`, a
+    (S, rows, N2) buffer a forward hook on layer 2 fills) of the layer-2 output.  bf16 mode: the oracle is
+    fed what the kernels feed the MFMA -- bf16-rounded inputs, drawn weights and hidden activations, fp32 bias.
+    Returns a dict of the measured errors and the tolerances they are judged by."""
+    import numpy as np
+    from oracle import oracle as orc
+    assert step.world == 1
+    dev = step.x.device
+    cell = step.gen.epoch_dev(dev)
+    torch.cuda.synchronize(dev)
+    e_dev = int(cell[0].item())                     # the epoch this replay's launches will read
+    out = step.run()
+    torch.cuda.synchronize(dev)
+    got = out.detach().float().cpu().numpy().copy()
+    e_after = int(cell[0].item())
+    S, T = step.samples, step.T
+    rnd = orc.bf16_round if mode == "bf16" else (lambda a: np.asarray(a, np.float32))
+    h0 = rnd(x_cpu[:rows].float().numpy())
+    pred = np.zeros((rows, DIMS[-1]), np.float64)
+    h2_ref = []
+    for s in range(S):
+        h = h0
+        for li, ((mw, rw, mb, rb), (kw, kb)) in enumerate(zip(post, step.keys)):
+            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, e_dev + kw.epoch_dev_delta, tuple(mw.shape))
+            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, e_dev + kb.epoch_dev_delta, tuple(mb.shape))
+            w = rnd(orc.sample_affine(mw.numpy(), rw.numpy(), ew))
+            b = orc.sample_affine(mb.numpy(), rb.numpy(), eb)
+            h = orc.linear(h, w, b)
+            if li < len(post) - 1:
+                h = rnd(np.maximum(h, 0.0))
+            if li == 1:
+                h2_ref.append(h)
+        pred += h
+    pred /= S
+    tensors = []
+    for mw, rw, mb, rb in post:
+        tensors += [(mw.numpy(), rw.numpy(), 0.0, 0.1), (mb.numpy(), rb.numpy(), 0.0, 0.1)]
+    kl_ref = orc.kl_divergence(tensors)
+    kl_got = float(got[T])
+    pm = got[T + 1:].reshape(BATCH, DIMS[-1])[:rows].astype(np.float64)
+    rms = float(np.sqrt((pred ** 2).mean()))
+    # bf16 mode: a drawn weight within the eps twin's 1e-6 of a bf16 rounding boundary rounds the other way on
+    # one side (one bf16 ulp on ~0.3 % of the weights) -- 4e-3 of the output scale covers that with margin
+    tol = 4e-3 if mode == "bf16" else 1e-5
+    res = {"mode": mode, "rows": rows, "epoch_dev": e_dev, "epoch_advanced": e_after == e_dev + 1,
+           "kl": kl_got, "kl_ref": kl_ref, "kl_rel_err": abs(kl_got - kl_ref) / abs(kl_ref), "kl_tol": 1e-5,
+           "pred_max_err": float(np.abs(pm - pred).max()), "pred_rms": rms, "tol": tol,
+           "pred_tol_abs": tol * max(1.0, rms)}
+    ok = res["kl_rel_err"] <= 1e-5 and res["pred_max_err"] <= res["pred_tol_abs"] and res["epoch_advanced"]
+    if tap is not None:
+        t = tap.detach().float().cpu().numpy().astype(np.float64)
+        ref = np.stack(h2_ref).astype(np.float64)
+        r2 = float(np.sqrt((ref ** 2).mean()))
+        res.update({"h2_max_err": float(np.abs(t - ref).max()), "h2_rms": r2, "h2_tol_abs": tol * max(1.0, r2)})
+        # a bf16-STORED activation may also round the other way on one side: one bf16 ulp of its value
+        ulp = np.abs(ref) * 2.0 ** -7 if mode == "bf16" else 0.0
+        ok = ok and bool((np.abs(t - ref) <= res["h2_tol_abs"] + ulp).all())
+    res["ok"] = bool(ok)
+    return res
+
+
 class TrainStep:
     """The reference's training-loop body (examples/MNIST/train.py:53-65): zero_grad, S-sample forward,
     KL, mean cross-entropy over the samples, backward, Adam.  Forward, KL, the whole backward of the
@@ -227,7 +294,7 @@ class TrainStep:
     bucketed all-reduces launched from backward hooks."""
 
     def __init__(self, net, x, rank, world, use_graph):
-        from bayesianneuralnetworks_amd import _lib, ops, optim, distributed as bd
+        from bayesianneuralnetworks_amd import ops, optim, distributed as bd
         from bayesianneuralnetworks_amd.nn import KLDivergence, fuse_kl_gradient
         fuse_kl_gradient(True)              # loss.backward() loop: KL gradient rides in the weight-gradient launches
         from bayesianneuralnetworks_amd._rng import default_generator
@@ -242,7 +309,6 @@ class TrainStep:
         self.opt = optim.Adam(net.parameters(), lr=1e-4)
         self.loss = torch.zeros((), device=dev)
         if use_graph:
-            lib = _lib.load()
             cell = default_generator.epoch_dev(dev)
             s = torch.cuda.Stream(dev)
             s.wait_stream(torch.cuda.current_stream(dev))
@@ -304,9 +370,25 @@ def time_steps(step, steps, warmup, world, dev):
     return dt
 
 
+def _time_launches(fn, dev, iters, warm=5):
+    """Average duration of fn() over `iters` back-to-back calls, by events on the launch stream (torch's current
+    stream IS the stream the C-ABI launches on: _lib.stream_ptr)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / iters
+
+
 def kernel_roofline(net, x, mode, dev, iters=50):
-    """Dominant kernel = the fused sampled GEMM of layer 2 (512 x 1200 x 1200, 8 samples in one
-    launch).  Average launch duration from events on the launch stream; algorithmic FLOPs."""
+    """Dominant kernel = the sampled layer 2 (512 x 1200 x 1200, 8 samples in one layer call).  Average
+    duration from events on the launch stream; algorithmic FLOPs."""
     from bayesianneuralnetworks_amd import _mc
     layer = net.layers[2]
     h = torch.randn(SAMPLES * BATCH, DIMS[1], device=dev).relu_()
@@ -314,29 +396,70 @@ def kernel_roofline(net, x, mode, dev, iters=50):
         h = h.bfloat16()          # the hidden activation the step really feeds this layer
     layer.compute = mode
     with torch.no_grad(), _mc.McContext(SAMPLES, BATCH, 0):
-        for _ in range(5):
-            layer(h)
-        torch.cuda.synchronize(dev)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            layer(h)
-        e1.record()
-        torch.cuda.synchronize(dev)
+        ms = _time_launches(lambda: layer(h), dev, iters)
     layer.compute = None
-    ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * SAMPLES * BATCH * DIMS[1] * DIMS[2]
     ach = flops / (ms * 1e-3) / 1e12
     # parameter bytes the launch must touch at least once: mu, rho of W and b
     pbytes = 8.0 * (DIMS[1] * DIMS[2] + DIMS[2])
-    return {"kernel": "k_linear_sym<sampled> layer2 512x1200x1200 x8 samples (one launch)", "bound": "mfma",
+    tag = "layer2_" + mode
+    traffic, src = pmc_traffic(tag)
+    return {"kernel": "sampled layer 2, 512x1200x1200 x8 samples (%s)" % tag, "bound": "mfma",
             "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s", "frac": round(ach / PEAK[mode], 4),
-            "traffic": TRAFFIC_PMC.get(mode), "avg_launch_us": round(ms * 1e3, 2),
+            "traffic": traffic, "traffic_source": src, "avg_launch_us": round(ms * 1e3, 2),
             "algorithmic_flop_per_launch": flops, "algorithmic_param_bytes_per_launch": pbytes,
-            "algorithmic_bytes_per_launch": pbytes + SAMPLES * BATCH * (DIMS[1] * (2 if mode == "bf16" else 4) + DIMS[2] * 4),
-            "note": "priced against the bf16 MFMA peak; the launch also makes 8 x 1.44 M eps draws (~10 us of VALU issue) and is bound by "
-                    "its per-SIMD issue stream / consume-phase latency chain (DESIGN.md 4): with explicit weights it takes as long"}
+            "algorithmic_bytes_per_launch": pbytes + SAMPLES * BATCH * (DIMS[1] * (2 if mode == "bf16" else 4) + DIMS[2] * 4)}
+
+
+def conv_roofline(which, mode, dev, iters=20):
+    """configs[2] / configs[3]: ONE NormalConv2d call over 8 MC samples (per-sample inputs), implicit GEMM.
+    Algorithmic FLOP = 2 * S * B * OH * OW * O * C * KH * KW."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalConv2d
+    from bayesianneuralnetworks_amd import _mc
+    B, C, O, HW, k, s, p = {"lenet": (1024, 64, 64, 6, 3, 2, 1), "cifar": (256, 128, 128, 4, 3, 1, 1)}[which]
+    torch.manual_seed(11)
+    layer = NormalConv2d(C, O, k, stride=s, padding=p).to(dev)
+    x = torch.randn(SAMPLES * B, C, HW, HW, device=dev)
+    OH = (HW + 2 * p - k) // s + 1
+    flops = 2.0 * SAMPLES * B * OH * OH * O * C * k * k
+    prev = bnn.get_compute()
+    bnn.set_compute(mode)
+    with torch.no_grad(), _mc.McContext(SAMPLES, B, 0):
+        ms = _time_launches(lambda: layer(x), dev, iters, warm=3)
+    bnn.set_compute(prev)
+    ach = flops / (ms * 1e-3) / 1e12
+    tag = "conv_%s_%s" % (which, mode)
+    traffic, src = pmc_traffic(tag)
+    abytes = 4.0 * x.numel() + 4.0 * SAMPLES * B * O * OH * OH + 8.0 * (O * C * k * k + O)
+    return {"kernel": "NormalConv2d %d->%d k%d s%d p%d on %dx%d, batch %d x 8 samples, one layer call (%s)"
+                      % (C, O, k, s, p, HW, HW, B, tag),
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s",
+            "frac": round(ach / PEAK[mode], 4), "traffic": traffic, "traffic_source": src,
+            "avg_launch_us": round(ms * 1e3, 2), "algorithmic_flop_per_launch": flops,
+            "algorithmic_bytes_per_launch": abytes}
+
+
+def wide_roofline(dev, iters=5):
+    """configs[4] layer: NormalLinear(4096, 4096) at batch 4096 in the fp32 parity mode, ONE MC sample per call
+    (the stack is 8 such layers; 1.0995 TFLOP per sample in all).  fp32-accurate contraction on bf16x3 splits."""
+    from bayesianneuralnetworks_amd.nn import NormalLinear
+    from bayesianneuralnetworks_amd import _mc
+    M = N = K = 4096
+    torch.manual_seed(12)
+    layer = NormalLinear(K, N).to(dev)
+    layer.compute = "f32"
+    x = torch.randn(M, K, device=dev)
+    with torch.no_grad(), _mc.McContext(1, M, 0):
+        ms = _time_launches(lambda: layer(x), dev, iters, warm=2)
+    flops = 2.0 * M * N * K
+    ach = flops / (ms * 1e-3) / 1e12
+    traffic, src = pmc_traffic("wide_f32")
+    return {"kernel": "NormalLinear 4096x4096, batch 4096, fp32 mode, 1 MC sample per call (draw once + contraction)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK["f32"], "unit": "TFLOP/s",
+            "frac": round(ach / PEAK["f32"], 4), "traffic": traffic, "traffic_source": src,
+            "avg_launch_us": round(ms * 1e3, 1), "algorithmic_flop_per_launch": flops,
+            "algorithmic_bytes_per_launch": 8.0 * (N * K + N) + 4.0 * M * (K + N)}
 
 
 def sampler_roofline(dev, iters=20):
@@ -348,17 +471,7 @@ def sampler_roofline(dev, iters=20):
     mu = torch.zeros(n, device=dev)
     rho = torch.full((n,), -2.0, device=dev)
     key = DrawKey(1, 1, 0, 1, 0)
-    for _ in range(3):
-        ops._sample_affine_philox_raw(mu, rho, key)
-    torch.cuda.synchronize(dev)
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops._sample_affine_philox_raw(mu, rho, key)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / iters
+    ms = _time_launches(lambda: ops._sample_affine_philox_raw(mu, rho, key), dev, iters, warm=3)
     gbs = 12.0 * n / (ms * 1e-3) / 1e9
     return {"kernel": "k_sample_affine_philox 64Mi scalars", "bound": "hbm", "achieved": round(gbs, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
@@ -374,17 +487,7 @@ def kl_roofline(dev, iters=20):
     rho = torch.full((n,), -2.0, device=dev)
     out = torch.empty(2, device=dev)
     with torch.no_grad():
-        for _ in range(3):
-            ops.kl_normal([mu], [rho], [(0.0, 0.1)], 1.0, out=out)
-        torch.cuda.synchronize(dev)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.kl_normal([mu], [rho], [(0.0, 0.1)], 1.0, out=out)
-        e1.record()
-        torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / iters
+        ms = _time_launches(lambda: ops.kl_normal([mu], [rho], [(0.0, 0.1)], 1.0, out=out), dev, iters, warm=3)
     gbs = 8.0 * n / (ms * 1e-3) / 1e9
     return {"kernel": "k_kl_partial + k_kl_final, 64Mi scalars", "bound": "hbm", "achieved": round(gbs, 1),
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
@@ -426,31 +529,77 @@ def cpu_baseline(post, x_cpu):
                       % (n, dt, model)}
 
 
-def main():
+# ------------------------------------------------------------------------------------------ rank spawn
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` outside a launcher: start N fresh rank processes of this script (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relay rank 0's JSON line.  Called BEFORE this
+    process has made any GPU call: the parent never initialises the GPU and nothing is re-exec'ed."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="forward", choices=["forward", "train"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1 headline: strong = the 8 global MC samples sharded 8/N per GPU (SURVEY 8e); weak = 8 per GPU")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-legs", action="store_true", help="skip the configs[2..4] / K1 / K3 roofline legs")
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("BNN_BENCH_DRYRUN"):
+        # spawn rehearsal for the CPU test-suite: no GPU call, no process group
+        print(json.dumps({"dryrun": True, "rank": rank, "world": world, "gpus": args.gpus}), flush=True)
+        return 0
+    ndev = torch.cuda.device_count()        # (counting devices does not initialise the GPU)
+    rehearsal = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" = RCCL over xGMI.  BNN_BENCH_BACKEND=gloo only rehearses the N > 1 code path on a
-        # box with fewer GPUs than ranks (ranks then share a card; the number is not a result).
-        torch.distributed.init_process_group(os.environ.get("BNN_BENCH_BACKEND", "nccl"))
-    local = local % max(1, torch.cuda.device_count())
+        # "nccl" = RCCL over xGMI.  With fewer GPUs than ranks (or BNN_BENCH_BACKEND=gloo) the N > 1 code path is only
+        # REHEARSED over gloo, ranks sharing a card: the number is then not a result and the line says so.
+        backend = os.environ.get("BNN_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
+        rehearsal = backend != "nccl"
+        torch.distributed.init_process_group(backend)
+    local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     import bayesianneuralnetworks_amd as bnn
-    from bayesianneuralnetworks_amd import _lib
+    from bayesianneuralnetworks_amd import _lib, distributed as bd
     _lib.load()                                     # fail loudly if the HIP library is missing
     post = posteriors(0)
     net = build_net(dev, post)
@@ -458,16 +607,29 @@ def main():
     x = x_cpu.to(dev)
     bnn.manual_seed(2)
 
-    results = {}
-    for mode in ([args.dtype] + (["f32"] if args.dtype != "f32" else [])):
+    strong = world > 1 and args.scaling == "strong" and SAMPLES % world == 0
+    results, checked, weak = {}, None, None
+    for mode in ([args.dtype] + (["f32"] if (args.dtype != "f32" and world == 1) else [])):
         bnn.set_compute(mode)
         # bf16 mode: the synthetic batch is resident in HBM as bf16 (the first layer would round its
         # A operand to bf16 anyway -- identical results, half the input stream); fp32 mode: fp32.
         x_in = x.bfloat16() if mode == "bf16" else x
-        step = Step(net, x_in, rank, world, not args.no_graph)
+        if strong:
+            s0, cnt = bd.shard_samples(SAMPLES, rank, world)
+            step = Step(net, x_in, rank, world, not args.no_graph, samples=cnt, sample0=s0, total_samples=SAMPLES)
+        else:
+            step = Step(net, x_in, rank, world, not args.no_graph)
         steps = args.steps if mode == args.dtype else max(10, args.steps // 4)
         dt = time_steps(step, steps, args.warmup, world, dev)
-        results[mode] = (world * SAMPLES * steps / dt, dt / steps * 1e3, steps)
+        results[mode] = ((SAMPLES if strong else world * SAMPLES) * steps / dt, dt / steps * 1e3, steps)
+        if mode == args.dtype and world == 1:
+            checked = oracle_check(step, post, x_cpu, mode)
+        if mode == args.dtype and strong:
+            wstep = Step(net, x_in, rank, world, not args.no_graph)
+            wdt = time_steps(wstep, steps, args.warmup, world, dev)
+            weak = (world * SAMPLES * steps / wdt, wdt / steps * 1e3)
+            del wstep
+        del step
     bnn.set_compute(args.dtype)
 
     # training step (own copy of the model: Adam moves the parameters)
@@ -482,21 +644,28 @@ def main():
 
     if rank == 0:
         val, ms, steps = results[args.dtype]
+        per_gpu = SAMPLES // world if strong else SAMPLES
         line = {
             "metric": "MC-samples/sec (node), 784-1200-1200-10 BayesianLinear MLP, batch 512",
             "value": round(val, 1), "unit": "MC-samples/s", "n_gpus": world, "steps": steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: MNIST-shape 784-1200-1200-10 NormalLinear MLP, batch 512, "
-                                   "8 MC samples per forward per GPU, KL once per forward, predictive mean; "
-                                   "bf16 operands / fp32 accumulate" if args.dtype == "bf16" else
-                                   "784-1200-1200-10 NormalLinear MLP, batch 512, 8 MC samples per forward per GPU, "
-                                   "fp32 parity mode (wide layers: bf16x3 splits on the bf16 MFMA, fp32-accurate)",
-                       "samples_per_step_per_gpu": SAMPLES, "batch": BATCH,
-                       "hip_graph": not args.no_graph, "launches_per_step": 4 if (world == 1 and os.environ.get("BNN_BENCH_KL", "carry") == "carry") else None,
+            "config": {"workload": ("configs[1]: MNIST-shape 784-1200-1200-10 NormalLinear MLP, batch 512, "
+                                    "%d MC samples per forward per GPU (%d in all), KL once per forward, predictive mean; "
+                                    % (per_gpu, SAMPLES if strong else world * SAMPLES)) +
+                                   ("bf16 operands / fp32 accumulate" if args.dtype == "bf16" else
+                                    "fp32 parity mode (wide layers: bf16x3 splits on the bf16 MFMA, fp32-accurate)"),
+                       "samples_per_step_per_gpu": per_gpu, "batch": BATCH, "hip_graph": not args.no_graph,
                        "collective": "one all-reduce of [6 KL sums, KL scalar, 512x10 prediction sum] fp32" if world > 1 else None},
         }
+        if rehearsal:
+            line["rehearsal"] = "ranks share %d GPU(s) over gloo: code-path rehearsal, not a result" % ndev
+        if weak is not None:
+            line["weak"] = {"value": round(weak[0], 1), "ms_per_step": round(weak[1], 4), "samples_per_step_per_gpu": SAMPLES,
+                            "note": "weak scaling: 8 MC samples on every GPU (global predictive mean over 8 N)"}
+        if checked is not None:
+            line["checked"] = checked
         if train is not None:
             line["train"] = {"value": round(train[0], 1), "unit": "MC-samples/s", "ms_per_step": round(train[1], 4),
                              "steps": train[2], "loss": round(train[3], 4), "hip_graph": (not args.no_graph) and world == 1,
@@ -505,19 +674,25 @@ def main():
                 line["forward"] = {"value": line["value"], "ms_per_step": line["ms_per_step"]}
                 line["metric"] = "MC-samples/sec (node), TRAINING step, 784-1200-1200-10 BayesianLinear MLP, batch 512"
                 line["value"], line["ms_per_step"], line["steps"] = line["train"]["value"], line["train"]["ms_per_step"], train[2]
+                line["scaling"] = "weak"
         if "f32" in results and args.dtype != "f32":
             line["f32"] = {"value": round(results["f32"][0], 1), "ms_per_step": round(results["f32"][1], 4),
                            "note": "same step in the 1e-5 parity mode (fp32 operands; wide layers as bf16x3 splits on the bf16 MFMA)"}
         line["roofline"] = kernel_roofline(net, x, args.dtype, dev)
-        line["roofline_sampler"] = sampler_roofline(dev)
-        line["roofline_kl"] = kl_roofline(dev)
+        if world == 1 and not args.no_legs:
+            line["roofline_sampler"] = sampler_roofline(dev)
+            line["roofline_kl"] = kl_roofline(dev)
+            line["roofline_conv_lenet"] = conv_roofline("lenet", args.dtype, dev)
+            line["roofline_conv_cifar"] = conv_roofline("cifar", args.dtype, dev)
+            line["roofline_wide_f32"] = wide_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(post, x_cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

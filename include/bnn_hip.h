@@ -47,7 +47,8 @@ enum {
     BNN_E_DTYPE = -3,     /* unknown dtype code */
     BNN_E_ALIGN = -4,     /* pointer not aligned to the element size */
     BNN_E_RANGE = -5,     /* value outside the supported range (e.g. >65535 samples) */
-    BNN_E_UNSUPPORTED = -6
+    BNN_E_UNSUPPORTED = -6,
+    BNN_E_DEVICE = -7     /* a kernel reported an internal error through the device error word (bnn_check_device) */
 };
 
 enum { BNN_F32 = 0, BNN_BF16 = 1 };
@@ -89,11 +90,17 @@ const char *bnn_last_error(void);    /* text of the last non-zero return on this
  * prove the HIP path ran). */
 uint64_t bnn_launch_count(void);
 
-/* Optional per-device scratch for kernels that split their reduction over workgroups (split-K of
- * the N <= 16 linear head): `bytes` >= 128 KiB of ZEROED device memory that stays valid until
- * replaced (ptr = NULL unregisters).  Without it those kernels run unsplit.  Host call, not
- * stream-ordered: register before launching. */
+/* Optional per-device scratch: `bytes` >= 128 KiB of ZEROED device memory that stays valid until replaced
+ * (ptr = NULL unregisters).  Layout: word 0 = the sticky DEVICE ERROR WORD, 64 KiB reserved, then slabs for
+ * the fixed-order partial sums of the backward kernels that split samples / rows over workgroups (without the
+ * workspace those entry points return BNN_E_UNSUPPORTED).  Host call, not stream-ordered: register before
+ * launching.  Launches use the workspace of the CURRENT device: make the operands' device current. */
 int bnn_set_workspace(int device, void *ptr, int64_t bytes);
+/* Reads (and clears) the device error word of `device` after synchronising `stream`: BNN_OK, or BNN_E_DEVICE
+ * when a kernel gave up on an internal protocol since the last check -- today only the bounded LDS hand-off
+ * waits of the fused linear kernel, which then skip their tile's store instead of storing numbers computed on
+ * an undrawn buffer.  A SYNCHRONISING host call (not graph-capturable): call it at a sync / check point. */
+int bnn_check_device(int device, void *stream);
 
 /* ---- K1: posterior draw --------------------------------------------------
  * replaces  WeightNormal.stddev / WeightNormal.sample

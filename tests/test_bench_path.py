@@ -1,0 +1,92 @@
+"""The path bench.py TIMES, pinned to the oracle.
+
+bench.Step for configs[1] -- 784-1200-1200-10 NormalLinear MLP, batch 512, 8 MC samples, bf16 operands with
+bf16 hidden activations, KL in two halves carried by the step's own launches, the device-epoch bump, ONE
+captured HIP graph -- is replayed three times.  After replay k the KL scalar, 64 rows of the predictive mean
+and 64 rows of the layer-2 output (a forward hook's copy, captured with the graph) are compared with the
+CPU oracle fed what the kernels feed the MFMA (bf16-rounded inputs / drawn weights / hidden activations) on
+the draw keys of THAT replay (epoch_dev = k).  Tolerances are stated in bench.oracle_check.
+
+Also here (CPU): `bench.py --gpus N` really starts N ranks.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`bench.py --gpus 2` with no launcher: two rank processes (the dry-run rehearsal makes no GPU call)."""
+    env = dict(os.environ, BNN_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"],
+                                  env=env, timeout=300)
+    line = json.loads(out.decode().strip().splitlines()[-1])
+    assert line == {"dryrun": True, "rank": 0, "world": 2, "gpus": 2}
+    # under a launcher (WORLD_SIZE set) the script is one rank and spawns nothing
+    env2 = dict(env, WORLD_SIZE="4", RANK="3", LOCAL_RANK="3")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, timeout=300)
+    assert json.loads(out.decode().strip().splitlines()[-1]) == {"dryrun": True, "rank": 3, "world": 4, "gpus": 4}
+
+
+def test_bench_strong_scaling_shards_cover_the_samples():
+    import bench
+    from bayesianneuralnetworks_amd import distributed as bd
+    for world in (1, 2, 4, 8):
+        ids = []
+        for r in range(world):
+            s0, cnt = bd.shard_samples(bench.SAMPLES, r, world)
+            ids += list(range(s0, s0 + cnt))
+        assert ids == list(range(bench.SAMPLES))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_timed_graph_replays_match_oracle(mode):
+    sys.path.insert(0, ROOT)
+    import bench
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    post = bench.posteriors(0)
+    net = bench.build_net(dev, post)
+    x_cpu = torch.randn(bench.BATCH, bench.DIMS[0], generator=torch.Generator().manual_seed(1))
+    x = x_cpu.to(dev)
+    bnn.manual_seed(2)
+    bnn.set_compute(mode)
+    rows = 64
+    tap = torch.zeros(bench.SAMPLES, rows, bench.DIMS[2], device=dev)
+
+    def hook(_m, _i, out):
+        tap.copy_(out.reshape(bench.SAMPLES, bench.BATCH, -1)[:, :rows])
+
+    h = net.layers[2].register_forward_hook(hook)
+    try:
+        n0 = lib.bnn_launch_count()
+        step = bench.Step(net, x.bfloat16() if mode == "bf16" else x, 0, 1, True)
+        assert step.graph is not None and lib.bnn_launch_count() > n0
+        prev = None
+        for k in range(3):
+            res = bench.oracle_check(step, post, x_cpu, mode, rows=rows, tap=tap)
+            print("replay %d: %s" % (k, json.dumps(res)))
+            assert res["epoch_advanced"]
+            assert res["kl_rel_err"] <= 1e-5, res
+            assert res["pred_max_err"] <= res["pred_tol_abs"], res
+            assert res["ok"], res
+            cur = step.packed.detach().cpu().numpy().copy()
+            if prev is not None:
+                # fresh noise on every replay: the predictions differ, the KL (eps-independent) does not
+                assert np.abs(cur[step.T + 1:] - prev[step.T + 1:]).max() > 1e-3
+                assert cur[step.T] == prev[step.T]
+            prev = cur
+    finally:
+        h.remove()
+        bnn.set_compute("f32")

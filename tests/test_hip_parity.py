@@ -1200,7 +1200,7 @@ def test_kl_gradient_fusion_is_opt_in_and_equivalent(env):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     assert l0 > 0 and l1 > 0          # (the saving is autograd's per-parameter accumulation adds, which are torch launches)
     from bayesianneuralnetworks_amd import ops
-    assert not ops._kl_pending
+    assert not ops._tls.kl_pending
 
 
 # ------------------------------------------------------------------ pruning

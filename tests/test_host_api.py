@@ -55,7 +55,7 @@ def test_cuda_only_ops_refuse_cpu_tensors():
     # the two-halves KL and the MC reduction that finishes it: no CPU path either, and nothing is left pending
     with pytest.raises(_lib.BnnHipError):
         ops.kl_normal_begin([torch.zeros(8)], [torch.zeros(8)], [(0.0, 0.1)], carry=True)
-    assert ops._kl_carry is None
+    assert ops._tls.kl_carry is None
     with pytest.raises(_lib.BnnHipError):
         ops.mc_mean(torch.zeros(2, 4))
 
@@ -83,6 +83,54 @@ def test_new_entry_points_reject_bad_arguments_without_launching():
     assert lib.bnn_linear_forward_sampled_kl(None, 0, 8, one, one, None, None, one, 0, 8, 4, 8, 8, 1, None, None, 0, 0,
                                              t, 1, one, None) < 0
     assert lib.bnn_launch_count() == n0
+
+
+def test_device_error_word_status_path_is_wired():
+    """bnn_check_device (the host half of the fused kernel's hand-off timeout report): exported, argument-checked, and a
+    device with no registered workspace has no word to read -- BNN_OK without touching a GPU."""
+    lib = _lib.load()
+    assert _lib.E_DEVICE == -7
+    assert lib.bnn_check_device(-1, None) == -5 and b"out of range" in lib.bnn_last_error()
+    assert lib.bnn_check_device(64, None) == -5
+    assert lib.bnn_check_device(63, None) == 0
+    header = open(os.path.join(ROOT, "include", "bnn_hip.h")).read()
+    assert "BNN_E_DEVICE = -7" in header
+    # the kernel side: every bounded wait reports through the word and skips its store
+    src = open(os.path.join(ROOT, "bayesianneuralnetworks_amd", "csrc", "bnn_linear.hip")).read()
+    assert src.count("handoff_ok &= lds_wait_ge(") == 2 and "kDevErrHandoffTimeout" in src
+
+
+def test_stream_ids_never_wrap():
+    from bayesianneuralnetworks_amd import _rng
+    import itertools
+    saved = _rng._stream_ids
+    try:
+        _rng._stream_ids = itertools.count(0xFFFF)
+        assert _rng.new_stream_id() == 0xFFFF
+        with pytest.raises(RuntimeError, match="exhausted"):
+            _rng.new_stream_id()
+    finally:
+        _rng._stream_ids = saved
+
+
+def test_kl_divergence_convenience_methods():
+    """`.kl_divergence()` of BASELINE.json's north_star == the reference's module form KLDivergence(n)(model), loss.py:30-38."""
+    torch.manual_seed(5)
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(6, 3, samples=2)
+            self.layers = torch.nn.Sequential(NormalLinear(6, 5), torch.nn.ReLU(), NormalLinear(5, 3))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    net = Net()
+    assert torch.equal(net.kl_divergence(7), KLDivergence(7)(net))
+    layer = net.layers[0]
+    per = [torch.distributions.kl.kl_divergence(p.dist, Normal(0, .1)).mean() for p in (layer.weight, layer.bias)]
+    assert torch.allclose(layer.kl_divergence(), torch.stack(per).mean())
+    assert bnn.nn.BayesianConv2d is NormalConv2d
 
 
 def test_exports_match_reference_names():
