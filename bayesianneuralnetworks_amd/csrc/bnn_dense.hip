@@ -1,0 +1,506 @@
+// bnn_dense.hip -- the draw-once path of the sampled linear layer (bf16 compute mode):
+//
+//   (1) k_draw_multi : K1 for EVERY posterior tensor of a forward in one launch -- w_s = mu + sigma(rho) * eps_s for all
+//       S MC samples, written as bf16 rows zero-padded to a multiple of 64 columns (biases: fp32) -- optionally
+//       carrying the KL's first pass as extra workgroups (it reads the same mu / rho);
+//   (2) k_dense_bf16 : y[s] = act(x[s] . w_s^T + b_s) on the drawn weights -- a dense MFMA GEMM whose operands both
+//       arrive by LDS-DMA;
+//   (3) k_head_bf16  : the same contraction for N <= 16 (the classifier head), K split over the waves of a workgroup.
+//
+// Why not fused (bnn_linear.hip draws inside the GEMM): one Philox block + Box-Muller + softplus is ~150 VALU issue
+// slots per 4 weights; inside the GEMM that stream shares each SIMD's issue port with the MFMAs and is paced by the
+// LDS hand-off between drawing and consuming waves (round-1 PMC: 48 % of a wave's timeline was hand-off; 200 workgroups
+// on 256 CUs).  Drawn once up front the draw runs on all 1024 SIMDs at full occupancy with sigma computed once for the
+// S samples of a weight (softplus: 36 of the ~150 slots), and the contraction becomes a GEMM bound by the L2 -> LDS
+// DMA rate and the MFMA pipe.  The 2 bytes per drawn weight this writes and re-reads stay in L2 / Infinity Cache.
+//
+// k_dense_bf16 structure (MI355X: 160 KB LDS, LDS-DMA, 4 SIMDs per CU):
+//   * 4 waves per workgroup (one per SIMD), all along M: wave w owns rows [w * 16 TM, (w + 1) * 16 TM) x all 16 TN
+//     columns of the tile.  Its A rows go into a PRIVATE 3-stage LDS ring filled by its own LDS-DMA pieces, so the
+//     only synchronisation on A is the wave's own counted s_waitcnt vmcnt.
+//   * the B tile (16 TN weight rows x 64 k) is shared: every wave DMAs a quarter of it, one raw s_barrier per 64-k
+//     step makes the four quarters visible (and frees the stage that is refilled next).
+//   * stages are requested two k-steps ahead: at the top of step t a wave waits for ITS pieces of step t
+//     (vmcnt(P): step t + 1's P pieces stay in flight), meets the barrier, issues step t + 2, computes step t.
+//   * LDS image of both operands: [row][8 x 16 B] with 16-B chunk c of row r at position c ^ (r & 7); the DMA writes
+//     linearly (lane l -> position l & 7 of row l >> 3 of its 8-row piece), so lane l FETCHES chunk (l & 7) ^ (l >> 3):
+//     eight lanes read one whole 128-B line.  ds_read_b128 fragment reads of this image are conflict-free.
+//   * v_mfma_f32_16x16x32_bf16; lane (i = l & 15, q = l >> 4) holds k = 8 q .. 8 q + 7 of a 32-k half-step = chunk
+//     4 h + q of the row: the DMA'd 16 B ARE the fragment.
+//   * K tail: A's chunk address is clamped inside the row (finite data), the weights are ZERO there (padded rows).
+//   * XCD map: blockIdx % 8 = MC sample (mod 8): a sample's activations and drawn weights (1.2 + 2.9 MB at the
+//     BASELINE layer) live in one XCD's 4 MB L2.
+//   * epilogue: bias, optional ReLU, then the wave's 16 TM x 16 TN results leave through its own A ring as whole
+//     16-B row chunks.
+#include <cstdlib>
+
+#include "bnn_device.hpp"
+#include "bnn_dma.hpp"
+#include "bnn_kl_body.hpp"
+
+namespace bnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------ (1) multi-tensor draw
+constexpr int kDrawMaxTensors = 8;
+
+struct DrawTensorDev {
+    const float *mu;
+    const float *rho;
+    void *out;
+    int64_t out_sample_stride;  // elements
+    int32_t rows, cols, ld;     // (rows, cols) posterior, output rows of ld >= cols elements (zeros beyond cols)
+    int32_t bf16;               // output dtype
+    int32_t first_item;         // first work item (8-column group) of this tensor within the launch
+    RngDev rng;
+};
+struct DrawLaunch {
+    DrawTensorDev t[kDrawMaxTensors];
+    int32_t ntensors;
+    int32_t nsamples;
+    int32_t total_items;
+    int32_t draw_blocks;        // workgroups >= draw_blocks run the KL's first pass
+    KlPiggy kl;
+};
+
+// One work item = 8 consecutive columns of one row = two Philox blocks; sigma once, then the S samples.
+__global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
+{
+    if ((int)blockIdx.x >= L.draw_blocks) {
+        kl_piggy_block(L.kl, (int)blockIdx.x - L.draw_blocks);
+        return;
+    }
+    const int item = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (item >= L.total_items) return;
+    int ti = 0;
+#pragma unroll
+    for (int i = 1; i < kDrawMaxTensors; ++i)
+        if (i < L.ntensors && item >= L.t[i].first_item) ti = i;
+    const DrawTensorDev &T = L.t[ti];
+    const int local = item - T.first_item;
+    const int gpr = T.ld >> 3;                       // 8-column groups per output row
+    const int row = local / gpr, c0 = (local - row * gpr) << 3;
+    const int S = L.nsamples;
+    const int64_t orow = (int64_t)row * T.ld + c0;
+    if (c0 >= T.cols) {
+        // padding columns: zeros (the dense kernel's K tail multiplies them with clamped, finite activations)
+        for (int s = 0; s < S; ++s) {
+            if (T.bf16) *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(T.out) + s * T.out_sample_stride + orow) = make_uint4(0u, 0u, 0u, 0u);
+            else {
+                float *o = reinterpret_cast<float *>(T.out) + s * T.out_sample_stride + orow;
+                for (int j = 0; j < 8; ++j) o[j] = 0.f;
+            }
+        }
+        return;
+    }
+    const int64_t e0 = (int64_t)row * T.cols + c0;   // flat element index: a multiple of 4 (cols % 4 == 0 or rows == 1)
+    const int nval = T.cols - c0 < 8 ? T.cols - c0 : 8;
+    float m[8], sg[8];
+    if (nval == 8 && (((reinterpret_cast<uintptr_t>(T.mu) | reinterpret_cast<uintptr_t>(T.rho)) & 15u) == 0) && (e0 & 3) == 0) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(T.mu + e0), m1 = *reinterpret_cast<const float4 *>(T.mu + e0 + 4);
+        const float4 r0 = *reinterpret_cast<const float4 *>(T.rho + e0), r1 = *reinterpret_cast<const float4 *>(T.rho + e0 + 4);
+        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+        sg[0] = sigma_draw(r0.x); sg[1] = sigma_draw(r0.y); sg[2] = sigma_draw(r0.z); sg[3] = sigma_draw(r0.w);
+        sg[4] = sigma_draw(r1.x); sg[5] = sigma_draw(r1.y); sg[6] = sigma_draw(r1.z); sg[7] = sigma_draw(r1.w);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m[j] = j < nval ? T.mu[e0 + j] : 0.f;
+            sg[j] = j < nval ? sigma_draw(T.rho[e0 + j]) : 0.f;
+        }
+    }
+    const uint32_t edev = rng_epoch_dev(T.rng);
+    const PhiloxKeys keys = philox_keys(T.rng.key0, T.rng.key1);
+    const uint32_t blk = (uint32_t)(e0 >> 2);
+    for (int s = 0; s < S; ++s) {
+        const uint32_t sample = T.rng.sample0 + (uint32_t)s;
+        const float4 za = eps4(T.rng, keys, edev, blk, sample);
+        const float4 zb = eps4(T.rng, keys, edev, blk + 1u, sample);
+        float w[8];
+        w[0] = fmaf(sg[0], za.x, m[0]); w[1] = fmaf(sg[1], za.y, m[1]);
+        w[2] = fmaf(sg[2], za.z, m[2]); w[3] = fmaf(sg[3], za.w, m[3]);
+        w[4] = fmaf(sg[4], zb.x, m[4]); w[5] = fmaf(sg[5], zb.y, m[5]);
+        w[6] = fmaf(sg[6], zb.z, m[6]); w[7] = fmaf(sg[7], zb.w, m[7]);
+        if (T.bf16) {
+            uint4 o;
+            o.x = pack_bf16x2(w[0], w[1]); o.y = pack_bf16x2(w[2], w[3]);
+            o.z = pack_bf16x2(w[4], w[5]); o.w = pack_bf16x2(w[6], w[7]);
+            uint16_t *dst = reinterpret_cast<uint16_t *>(T.out) + s * T.out_sample_stride + orow;
+            if (nval == 8) *reinterpret_cast<uint4 *>(dst) = o;
+            else {
+                // ragged end of a row whose padding starts inside this group: values, then zeros up to the group's end
+                const uint32_t ww[4] = {o.x, o.y, o.z, o.w};
+                for (int j = 0; j < 8; ++j) {
+                    const uint16_t h = (uint16_t)(ww[j >> 1] >> ((j & 1) * 16));
+                    if (c0 + j < T.ld) dst[j] = j < nval ? h : (uint16_t)0;
+                }
+            }
+        } else {
+            float *dst = reinterpret_cast<float *>(T.out) + s * T.out_sample_stride + orow;
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < T.ld) dst[j] = j < nval ? w[j] : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ (2) dense GEMM
+struct DenseParams {
+    const uint16_t *A;          // (S or 1) x M x lda bf16
+    int64_t a_sample_stride;    // elements; 0 = input shared by all samples
+    int64_t lda;
+    const uint16_t *W;          // S x N x ldw bf16, zero beyond K up to ldw >= roundup(K, 64)
+    int64_t w_sample_stride;
+    int64_t ldw;
+    const float *bias;          // S x N fp32 or NULL
+    int64_t bias_sample_stride;
+    void *Y;                    // S x M x ldy, fp32 or bf16
+    int64_t y_sample_stride;
+    int64_t ldy;
+    int32_t M, N, K, S;
+    int32_t ntm, ntn;
+    int32_t flags;              // BNN_FLAG_RELU, BNN_FLAG_Y_BF16
+};
+
+// one LDS-DMA piece, scalar-base form: 64 lanes x 16 B from (base + voff) land at lds + 16 * lane
+__device__ __forceinline__ void dma_piece(const void *base, uint32_t voff, uint32_t lds)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds) : "memory");
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void k_dense_bf16(const DenseParams p)
+{
+    constexpr int NWV = 4;
+    constexpr int WM = 16 * TM, BM = NWV * WM, BN = 16 * TN;
+    constexpr int ST = 3;                               // ring stages
+    constexpr int A_PIECES = WM / 8;                    // 1-KiB pieces (8 rows x 128 B) per wave per stage
+    constexpr int B_ROWS = (BN + 31) / 32 * 32;         // padded so that every wave issues the same number of pieces
+    constexpr int B_PIECES = B_ROWS / 8 / NWV;          // per wave per stage
+    constexpr int P = A_PIECES + B_PIECES;              // VMEM ops per wave per stage
+    constexpr int A_STAGE = WM * 128;                   // bytes
+    constexpr int B_STAGE = B_ROWS * 128;
+    constexpr int A_RING = ST * A_STAGE;
+    static_assert(A_RING >= WM * BN * 4, "the wave's A ring must hold its output tile (epilogue staging)");
+    __shared__ __attribute__((aligned(16))) char lds[NWV * A_RING + ST * B_STAGE];
+
+    // ---- block decode: sample -> XCD when the samples fill the 8 XCDs
+    const int per_s = p.ntm * p.ntn;
+    int s, t;
+    {
+        const int L = (int)blockIdx.x;
+        if (p.S % 8 == 0) {
+            const int idx = L >> 3;
+            s = (L & 7) + 8 * (idx / per_s);
+            t = idx % per_s;
+        } else {
+            s = L / per_s;
+            t = L % per_s;
+        }
+    }
+    const int mt = t / p.ntn, panel = t % p.ntn;
+    const int m0 = mt * BM, n0 = panel * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fq = lane >> 4;
+
+    char *a_ring = lds + wave * A_RING;
+    char *b_ring = lds + NWV * A_RING;
+    const uint32_t a_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(a_ring));
+    const uint32_t b_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(b_ring)) + (uint32_t)(wave * B_PIECES) * 1024u;
+
+    // ---- DMA sources.  Lane l writes position l & 7 of row l >> 3 of its piece and therefore fetches chunk
+    // (l & 7) ^ (l >> 3) of that row (the image's XOR swizzle, applied on the source address).
+    const int prow = lane >> 3;
+    const int schunk = (lane & 7) ^ prow;
+    const char *a_base = reinterpret_cast<const char *>(p.A + (int64_t)s * p.a_sample_stride);
+    const char *w_base = reinterpret_cast<const char *>(p.W + (int64_t)s * p.w_sample_stride);
+    uint32_t a_off[A_PIECES], b_off[B_PIECES];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) {
+        int m = m0 + wave * WM + 8 * j + prow;
+        m = m < p.M ? m : p.M - 1;                      // rows >= M: clamped, results never stored
+        a_off[j] = (uint32_t)((int64_t)m * p.lda * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PIECES; ++j) {
+        int n = n0 + (wave * B_PIECES + j) * 8 + prow;
+        n = n < p.N ? n : p.N - 1;                      // rows >= N (and the tile's padding rows): clamped
+        b_off[j] = (uint32_t)((int64_t)n * p.ldw * 2) + 16u * (uint32_t)schunk;
+    }
+    const uint32_t a_colmax = (uint32_t)(p.K * 2 - 16);  // last legal 16-B chunk of an activation row
+    auto issue = [&](int kt) {
+        const int stage = kt % ST;
+        const uint32_t colA0 = (uint32_t)(kt * 128 + 16 * schunk);
+        const uint32_t colA = colA0 < a_colmax ? colA0 : a_colmax;       // k >= K: any finite chunk (the weights are 0 there)
+        const uint32_t colB = (uint32_t)(kt * 128);
+#pragma unroll
+        for (int j = 0; j < A_PIECES; ++j)
+            dma_piece(a_base, a_off[j] + colA, a_lds + (uint32_t)(stage * A_STAGE + j * 1024));
+#pragma unroll
+        for (int j = 0; j < B_PIECES; ++j)
+            dma_piece(w_base, b_off[j] + colB, b_lds + (uint32_t)(stage * B_STAGE + j * 1024));
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + 63) / 64;
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of step kt have landed (step kt + 1's P pieces may still be in flight) ...
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and after the barrier so have the other waves' quarters of B; every wave has also finished reading
+        // step kt - 1, whose stage is the one refilled next
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue(kt + 2);
+        const char *As = a_ring + (kt % ST) * A_STAGE;
+        const char *Bs = b_ring + (kt % ST) * B_STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 af[TM], bfr[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int row = b * 16 + fi;
+                bfr[b] = *reinterpret_cast<const uint4 *>(Bs + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = a * 16 + fi;
+                af[a] = *reinterpret_cast<const uint4 *>(As + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
+                                                                        __builtin_bit_cast(bf16x8, bfr[b]), acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias, activation, store (accumulator lane (i, q), register r = row 4 q + r, column i of a 16 x 16 block)
+    const bool ybf = (p.flags & BNN_FLAG_Y_BF16) != 0;
+    const bool relu = (p.flags & BNN_FLAG_RELU) != 0;
+    const float *bias = p.bias ? p.bias + (int64_t)s * p.bias_sample_stride : nullptr;
+    const int esz = ybf ? 2 : 4;
+    const int64_t ybase = (int64_t)s * p.y_sample_stride * esz;
+    const int mw = m0 + wave * WM;
+    const bool wide = n0 + BN <= p.N && mw + WM <= p.M && (p.ldy * esz) % 16 == 0 && (n0 * esz) % 16 == 0 &&
+                      ((reinterpret_cast<uintptr_t>(p.Y) + ybase) & 15u) == 0;
+    if (wide) {
+        // every wave passed the last barrier after ITS last read of the A ring: the ring is free
+        char *T = a_ring;
+        const int pitch = BN * esz;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const float bv = bias ? bias[n0 + b * 16 + fi] : 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[a][b][r] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    char *q = T + (a * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * esz;
+                    if (ybf) *reinterpret_cast<uint16_t *>(q) = f2bf(v);
+                    else *reinterpret_cast<float *>(q) = v;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's ds_writes before its ds_reads
+        __builtin_amdgcn_wave_barrier();
+        const int cpr = pitch / 16;
+        char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)mw * p.ldy + n0) * esz;
+        for (int c = lane; c < WM * cpr; c += 64) {
+            const int row = c / cpr, cc = c - row * cpr;
+            *reinterpret_cast<uint4 *>(Y8 + (int64_t)row * p.ldy * esz + cc * 16) = *reinterpret_cast<const uint4 *>(T + row * pitch + cc * 16);
+        }
+        return;
+    }
+    float *Yf = reinterpret_cast<float *>(p.Y) + (int64_t)s * p.y_sample_stride;
+    uint16_t *Yh = reinterpret_cast<uint16_t *>(p.Y) + (int64_t)s * p.y_sample_stride;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + b * 16 + fi;
+        if (n >= p.N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mw + a * 16 + fq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[a][b][r] + bv;
+                if (relu) v = fmaxf(v, 0.f);
+                if (ybf) Yh[(int64_t)m * p.ldy + n] = f2bf(v);
+                else Yf[(int64_t)m * p.ldy + n] = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ (3) narrow head
+// N <= 16 (the 10-way classifier head): 16 rows x 16 columns per workgroup, K split over its 4 waves; fragments are
+// loaded straight to registers (one MFMA per 32 k: nothing to reuse through LDS), every load of a wave's K range is
+// requested before the first use.  The four partial tiles are added in wave order through LDS (fixed order: bitwise
+// reproducible).  grid = S * ceil(M / 16): the BASELINE head is 256 workgroups, one per CU.
+constexpr int kHeadMaxSteps = 16;     // 32-k steps per wave: K <= 4 * 16 * 32 = 2048
+
+__global__ __launch_bounds__(256) void k_head_bf16(const DenseParams p)
+{
+    __shared__ float red[4][16][17];
+    const int ntm = p.ntm;
+    const int s = (int)blockIdx.x / ntm, mt = (int)blockIdx.x % ntm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fq = lane >> 4;
+    const int nk = (p.K + 31) / 32;
+    const int per = (nk + 3) / 4;
+    const int k0 = wave * per, k1 = (k0 + per < nk) ? k0 + per : nk;
+    int m = mt * 16 + fi;
+    m = m < p.M ? m : p.M - 1;
+    int n = fi < p.N ? fi : p.N - 1;
+    const uint16_t *arow = p.A + (int64_t)s * p.a_sample_stride + (int64_t)m * p.lda;
+    const uint16_t *wrow = p.W + (int64_t)s * p.w_sample_stride + (int64_t)n * p.ldw;
+    uint4 af[kHeadMaxSteps], bfr[kHeadMaxSteps];
+    const int kmax = p.K - 8;
+#pragma unroll
+    for (int i = 0; i < kHeadMaxSteps; ++i) {
+        const int kt = k0 + i;
+        int ka = kt * 32 + 8 * fq;
+        const int kb = ka;
+        ka = ka < kmax ? ka : kmax;                 // k >= K: clamped (finite) activations x zero-padded weights
+        if (kt < k1) {
+            af[i] = *reinterpret_cast<const uint4 *>(arow + ka);
+            bfr[i] = *reinterpret_cast<const uint4 *>(wrow + kb);
+        } else {
+            af[i] = make_uint4(0u, 0u, 0u, 0u);
+            bfr[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kHeadMaxSteps; ++i)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bfr[i]), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][fq * 4 + r][fi] = acc[r];
+    __syncthreads();
+    // 256 threads = 16 x 16 outputs
+    const int row = tid >> 4, col = tid & 15;
+    const int mo = mt * 16 + row;
+    if (mo < p.M && col < p.N) {
+        float v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+        if (p.bias) v += p.bias[(int64_t)s * p.bias_sample_stride + col];
+        if (p.flags & BNN_FLAG_RELU) v = fmaxf(v, 0.f);
+        if (p.flags & BNN_FLAG_Y_BF16) reinterpret_cast<uint16_t *>(p.Y)[(int64_t)s * p.y_sample_stride + (int64_t)mo * p.ldy + col] = f2bf(v);
+        else reinterpret_cast<float *>(p.Y)[(int64_t)s * p.y_sample_stride + (int64_t)mo * p.ldy + col] = v;
+    }
+}
+
+static inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+}  // namespace bnn
+
+using namespace bnn;
+
+extern "C" {
+
+int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
+                   const bnn_kl_tensor_t *kl_tensors, int kl_ntensors, void *kl_workspace, void *stream)
+{
+    const char *who = "bnn_draw_multi";
+    if (!tensors) { set_error("%s: NULL tensors", who); return BNN_E_NULL; }
+    if (ntensors < 1 || ntensors > kDrawMaxTensors) { set_error("%s: 1 .. %d tensors per call", who, kDrawMaxTensors); return BNN_E_RANGE; }
+    if (nsamples < 1) { set_error("%s: nsamples < 1", who); return BNN_E_SHAPE; }
+    DrawLaunch L{};
+    L.ntensors = ntensors;
+    L.nsamples = nsamples;
+    int64_t items = 0;
+    for (int i = 0; i < ntensors; ++i) {
+        const bnn_draw_tensor_t &t = tensors[i];
+        if (!t.mu || !t.rho || !t.out) { set_error("%s: tensor %d: NULL pointer", who, i); return BNN_E_NULL; }
+        if (t.rows < 1 || t.cols < 1 || t.ld < t.cols || t.rows > 0x7FFFFFFF || t.ld > 0x7FFFFFFF) { set_error("%s: tensor %d: bad extent", who, i); return BNN_E_SHAPE; }
+        if (t.out_dtype != BNN_F32 && t.out_dtype != BNN_BF16) { set_error("%s: tensor %d: unknown dtype", who, i); return BNN_E_DTYPE; }
+        // a Philox block is 4 consecutive elements of the flat tensor and a work item 8 columns of one row
+        if (t.rows > 1 && t.cols % 4 != 0) { set_error("%s: tensor %d: cols %% 4 != 0 (use bnn_sample_affine_philox)", who, i); return BNN_E_UNSUPPORTED; }
+        if (t.ld % 8 != 0 && t.rows > 1) { set_error("%s: tensor %d: ld %% 8 != 0", who, i); return BNN_E_UNSUPPORTED; }
+        if (t.out_dtype == BNN_BF16 && (!al16(t.out) || t.out_sample_stride % 8 != 0 || t.ld % 8 != 0)) { set_error("%s: tensor %d: bf16 output needs 16-B aligned rows", who, i); return BNN_E_ALIGN; }
+        if ((reinterpret_cast<uintptr_t>(t.mu) | reinterpret_cast<uintptr_t>(t.rho) | reinterpret_cast<uintptr_t>(t.out)) & 3u) { set_error("%s: tensor %d: misaligned pointer", who, i); return BNN_E_ALIGN; }
+        const int rc = check_rng(&t.rng, nsamples);
+        if (rc) { set_error("%s: tensor %d: bad rng", who, i); return rc; }
+        DrawTensorDev &d = L.t[i];
+        d.mu = t.mu; d.rho = t.rho; d.out = t.out; d.out_sample_stride = t.out_sample_stride;
+        d.rows = (int32_t)t.rows; d.cols = (int32_t)t.cols; d.ld = (int32_t)t.ld; d.bf16 = t.out_dtype == BNN_BF16;
+        d.first_item = (int32_t)items;
+        d.rng = make_rng(&t.rng);
+        items += t.rows * ((t.ld + 7) / 8);
+        if (items > 0x7FFFFF00) { set_error("%s: too many elements for one call", who); return BNN_E_RANGE; }
+    }
+    L.total_items = (int32_t)items;
+    L.draw_blocks = (int32_t)((items + 255) / 256);
+    int64_t grid = L.draw_blocks;
+    if (kl_tensors && kl_ntensors > 0) {
+        if (!kl_plan_piggy(kl_tensors, kl_ntensors, kl_workspace, L.kl)) {
+            set_error("%s: the KL first pass cannot ride along (more than %d tensors, bad prior or no workspace): launch bnn_kl_forward_partial", who, kKlPiggyMax);
+            return BNN_E_UNSUPPORTED;
+        }
+        grid += L.kl.nblocks;
+    }
+    hipLaunchKernelGGL(k_draw_multi, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, L);
+    return check_launch(who);
+}
+
+int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
+                      const void *w, int64_t w_sample_stride, int64_t ldw,
+                      const float *b, int64_t b_sample_stride,
+                      void *y, int64_t y_sample_stride, int64_t ldy,
+                      int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream)
+{
+    const char *who = "bnn_dense_forward";
+    if (M == 0 && N >= 1 && K >= 1 && nsamples >= 1) return BNN_OK;
+    if (!x || !w || !y) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldy < N) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    if (flags & ~(BNN_FLAG_RELU | BNN_FLAG_Y_BF16)) { set_error("%s: unknown flags", who); return BNN_E_UNSUPPORTED; }
+    const int64_t kp = (K + 63) / 64 * 64;
+    if (K % 8 != 0 || ldx % 8 != 0 || x_sample_stride % 8 != 0 || ldw % 8 != 0 || w_sample_stride % 8 != 0 || ldw < kp || !al16(x) || !al16(w)) {
+        set_error("%s: needs K %% 8 == 0, 16-B aligned bf16 rows, and weight rows zero-padded to ldw >= roundup(K, 64)", who);
+        return BNN_E_UNSUPPORTED;
+    }
+    if (M * ldx * 2 >= ((int64_t)1 << 32) || N * ldw * 2 >= ((int64_t)1 << 32)) { set_error("%s: one sample's operand exceeds 4 GiB", who); return BNN_E_RANGE; }
+    const bool ybf = (flags & BNN_FLAG_Y_BF16) != 0;
+    if (reinterpret_cast<uintptr_t>(y) & (ybf ? 1u : 3u)) { set_error("%s: misaligned output", who); return BNN_E_ALIGN; }
+    DenseParams p{};
+    p.A = reinterpret_cast<const uint16_t *>(x); p.a_sample_stride = x_sample_stride; p.lda = ldx;
+    p.W = reinterpret_cast<const uint16_t *>(w); p.w_sample_stride = w_sample_stride; p.ldw = ldw;
+    p.bias = b; p.bias_sample_stride = b_sample_stride;
+    p.Y = y; p.y_sample_stride = y_sample_stride; p.ldy = ldy;
+    p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.flags = flags;
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 16 && K <= 4 * kHeadMaxSteps * 32) {
+        p.ntm = (int32_t)((M + 15) / 16);
+        p.ntn = 1;
+        hipLaunchKernelGGL(k_head_bf16, dim3((unsigned)((int64_t)p.ntm * nsamples)), dim3(256), 0, st, p);
+        return check_launch(who);
+    }
+    static const int force_tn = [] { const char *e = getenv("BNN_DENSE_TN"); return e ? atoi(e) : 0; }();
+    // tile: 256 rows x 16 TN columns.  TN = 5 (80 columns) divides the BASELINE width 1200 exactly: 2 x 15 x 8 = 240
+    // workgroups on 256 CUs; wide layers take 128 columns.
+    int tn = (N % 80 == 0 || N < 128) ? 5 : 8;
+    if (force_tn == 5 || force_tn == 8) tn = force_tn;
+    const int bn = 16 * tn;
+    p.ntm = (int32_t)((M + 255) / 256);
+    p.ntn = (int32_t)((N + bn - 1) / bn);
+    const int64_t grid = (int64_t)p.ntm * p.ntn * nsamples;
+    if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
+    if (tn == 5) hipLaunchKernelGGL((k_dense_bf16<4, 5>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_dense_bf16<4, 8>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    return check_launch(who);
+}
+
+}  // extern "C"
