@@ -56,6 +56,13 @@ class KlFuse(ctypes.Structure):
                 ("scale_b", ctypes.c_float), ("prior_mu_b", ctypes.c_float), ("prior_sigma_b", ctypes.c_float)]
 
 
+class DrawTensor(ctypes.Structure):
+    """bnn_draw_tensor_t"""
+    _fields_ = [("mu", ctypes.c_void_p), ("rho", ctypes.c_void_p), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64),
+                ("out", ctypes.c_void_p), ("ld", ctypes.c_int64), ("out_sample_stride", ctypes.c_int64),
+                ("out_dtype", ctypes.c_int), ("rng", Rng)]
+
+
 class Conv2dShape(ctypes.Structure):
     """bnn_conv2d_shape_t"""
     _fields_ = [(n, ctypes.c_int32) for n in
@@ -93,6 +100,8 @@ SIGNATURES = {
                                           _i64, _int, _rngp, _rngp, _int, _int, _p]),
     "bnn_linear_forward_sampled_kl": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64,
                                              _i64, _int, _rngp, _rngp, _int, _int, ctypes.POINTER(KlTensor), _int, _p, _p]),
+    "bnn_draw_multi": (_int, [ctypes.POINTER(DrawTensor), _int, _int, ctypes.POINTER(KlTensor), _int, _p, _p]),
+    "bnn_dense_forward": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p]),
     "bnn_linear_forward": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,
                                   _int, _int, _int, _p]),
     "bnn_linear_backward_input_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int,
@@ -222,13 +231,13 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def require_cuda_act(t, name):
-    """activation tensor: contiguous CUDA fp32 or bf16"""
+def require_cuda_act(t, name, contiguous=True):
+    """activation tensor: CUDA fp32 or bf16, contiguous unless the caller has checked its row layout itself"""
     if not t.is_cuda:
         raise BnnHipError("%s must be a CUDA/HIP tensor" % name)
     if t.dtype not in (torch.float32, torch.bfloat16):
         raise BnnHipError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
-    if not t.is_contiguous():
+    if contiguous and not t.is_contiguous():
         raise BnnHipError("%s must be contiguous" % name)
 
 

@@ -33,6 +33,7 @@
 //   * epilogue: bias, optional ReLU, then the wave's 16 TM x 16 TN results leave through its own A ring as whole
 //     16-B row chunks.
 #include <cstdlib>
+#include <type_traits>
 
 #include "bnn_device.hpp"
 #include "bnn_dma.hpp"
@@ -66,81 +67,96 @@ struct DrawLaunch {
 };
 
 // One work item = 8 consecutive columns of one row = two Philox blocks; sigma once, then the S samples.
+// A tensor's items start at a multiple of 256 (first_item): a workgroup works on ONE tensor, whose descriptor is then
+// wave-uniform -- read once with scalar loads and kept in SGPRs.  (Indexed per thread, L.t[ti] was re-read from the
+// kernel-argument segment by vector loads inside the sample loop -- the stores may alias it as far as the compiler
+// knows -- and every s_waitcnt vmcnt(0) on those loads also waited for the previous sample's store: PMC showed the
+// waves parked 47 % of the time.)
+template <int U>
 __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
 {
     if ((int)blockIdx.x >= L.draw_blocks) {
         kl_piggy_block(L.kl, (int)blockIdx.x - L.draw_blocks);
         return;
     }
-    const int item = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (item >= L.total_items) return;
+    const int item0 = (int)blockIdx.x * 256;
     int ti = 0;
 #pragma unroll
     for (int i = 1; i < kDrawMaxTensors; ++i)
-        if (i < L.ntensors && item >= L.t[i].first_item) ti = i;
-    const DrawTensorDev &T = L.t[ti];
-    const int local = item - T.first_item;
-    const int gpr = T.ld >> 3;                       // 8-column groups per output row
-    const int row = local / gpr, c0 = (local - row * gpr) << 3;
+        if (i < L.ntensors && item0 >= L.t[i].first_item) ti = i;
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    // the descriptor, copied out of the argument block once
+    const float *const t_mu = L.t[ti].mu;
+    const float *const t_rho = L.t[ti].rho;
+    char *const t_out = reinterpret_cast<char *>(L.t[ti].out);
+    const int64_t t_stride = L.t[ti].out_sample_stride;
+    const int t_rows = L.t[ti].rows, t_cols = L.t[ti].cols, t_ld = L.t[ti].ld;
+    const bool t_bf16 = L.t[ti].bf16 != 0;
+    const RngDev rng = L.t[ti].rng;
     const int S = L.nsamples;
-    const int64_t orow = (int64_t)row * T.ld + c0;
-    if (c0 >= T.cols) {
+    const int local = item0 + (int)threadIdx.x - L.t[ti].first_item;
+    const int gpr = (t_ld + 7) >> 3;                 // 8-column groups per output row
+    const int row = local / gpr, c0 = (local - row * gpr) << 3;
+    if (row >= t_rows) return;
+    const int64_t orow = (int64_t)row * t_ld + c0;
+    const int esz = t_bf16 ? 2 : 4;
+    char *const dst0 = t_out + orow * esz;
+    const int64_t sbytes = t_stride * esz;
+    if (c0 >= t_cols) {
         // padding columns: zeros (the dense kernel's K tail multiplies them with clamped, finite activations)
         for (int s = 0; s < S; ++s) {
-            if (T.bf16) *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(T.out) + s * T.out_sample_stride + orow) = make_uint4(0u, 0u, 0u, 0u);
-            else {
-                float *o = reinterpret_cast<float *>(T.out) + s * T.out_sample_stride + orow;
-                for (int j = 0; j < 8; ++j) o[j] = 0.f;
-            }
+            if (t_bf16) *reinterpret_cast<uint4 *>(dst0 + s * sbytes) = make_uint4(0u, 0u, 0u, 0u);
+            else
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < t_ld) reinterpret_cast<float *>(dst0 + s * sbytes)[j] = 0.f;
         }
         return;
     }
-    const int64_t e0 = (int64_t)row * T.cols + c0;   // flat element index: a multiple of 4 (cols % 4 == 0 or rows == 1)
-    const int nval = T.cols - c0 < 8 ? T.cols - c0 : 8;
+    const int64_t e0 = (int64_t)row * t_cols + c0;   // flat element index: a multiple of 4 (cols % 4 == 0 or rows == 1)
+    const int nval = t_cols - c0 < 8 ? t_cols - c0 : 8;
+    const bool full = nval == 8 && (((reinterpret_cast<uintptr_t>(t_mu) | reinterpret_cast<uintptr_t>(t_rho)) & 15u) == 0) && (e0 & 3) == 0;
     float m[8], sg[8];
-    if (nval == 8 && (((reinterpret_cast<uintptr_t>(T.mu) | reinterpret_cast<uintptr_t>(T.rho)) & 15u) == 0) && (e0 & 3) == 0) {
-        const float4 m0 = *reinterpret_cast<const float4 *>(T.mu + e0), m1 = *reinterpret_cast<const float4 *>(T.mu + e0 + 4);
-        const float4 r0 = *reinterpret_cast<const float4 *>(T.rho + e0), r1 = *reinterpret_cast<const float4 *>(T.rho + e0 + 4);
+    if (full) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(t_mu + e0), m1 = *reinterpret_cast<const float4 *>(t_mu + e0 + 4);
+        const float4 r0 = *reinterpret_cast<const float4 *>(t_rho + e0), r1 = *reinterpret_cast<const float4 *>(t_rho + e0 + 4);
         m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
         sg[0] = sigma_draw(r0.x); sg[1] = sigma_draw(r0.y); sg[2] = sigma_draw(r0.z); sg[3] = sigma_draw(r0.w);
         sg[4] = sigma_draw(r1.x); sg[5] = sigma_draw(r1.y); sg[6] = sigma_draw(r1.z); sg[7] = sigma_draw(r1.w);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            m[j] = j < nval ? T.mu[e0 + j] : 0.f;
-            sg[j] = j < nval ? sigma_draw(T.rho[e0 + j]) : 0.f;
+            m[j] = j < nval ? t_mu[e0 + j] : 0.f;
+            sg[j] = j < nval ? sigma_draw(t_rho[e0 + j]) : 0.f;
         }
     }
-    const uint32_t edev = rng_epoch_dev(T.rng);
-    const PhiloxKeys keys = philox_keys(T.rng.key0, T.rng.key1);
+    const uint32_t edev = rng_epoch_dev(rng);
+    const PhiloxKeys keys = philox_keys(rng.key0, rng.key1);
     const uint32_t blk = (uint32_t)(e0 >> 2);
+    const bool vec_store = t_bf16 && nval == 8;
+#pragma unroll U
     for (int s = 0; s < S; ++s) {
-        const uint32_t sample = T.rng.sample0 + (uint32_t)s;
-        const float4 za = eps4(T.rng, keys, edev, blk, sample);
-        const float4 zb = eps4(T.rng, keys, edev, blk + 1u, sample);
+        const uint32_t sample = rng.sample0 + (uint32_t)s;
+        const float4 za = eps4(rng, keys, edev, blk, sample);
+        const float4 zb = eps4(rng, keys, edev, blk + 1u, sample);
         float w[8];
         w[0] = fmaf(sg[0], za.x, m[0]); w[1] = fmaf(sg[1], za.y, m[1]);
         w[2] = fmaf(sg[2], za.z, m[2]); w[3] = fmaf(sg[3], za.w, m[3]);
         w[4] = fmaf(sg[4], zb.x, m[4]); w[5] = fmaf(sg[5], zb.y, m[5]);
         w[6] = fmaf(sg[6], zb.z, m[6]); w[7] = fmaf(sg[7], zb.w, m[7]);
-        if (T.bf16) {
+        char *dst = dst0 + s * sbytes;
+        if (vec_store) {
             uint4 o;
             o.x = pack_bf16x2(w[0], w[1]); o.y = pack_bf16x2(w[2], w[3]);
             o.z = pack_bf16x2(w[4], w[5]); o.w = pack_bf16x2(w[6], w[7]);
-            uint16_t *dst = reinterpret_cast<uint16_t *>(T.out) + s * T.out_sample_stride + orow;
-            if (nval == 8) *reinterpret_cast<uint4 *>(dst) = o;
-            else {
-                // ragged end of a row whose padding starts inside this group: values, then zeros up to the group's end
-                const uint32_t ww[4] = {o.x, o.y, o.z, o.w};
-                for (int j = 0; j < 8; ++j) {
-                    const uint16_t h = (uint16_t)(ww[j >> 1] >> ((j & 1) * 16));
-                    if (c0 + j < T.ld) dst[j] = j < nval ? h : (uint16_t)0;
-                }
-            }
+            *reinterpret_cast<uint4 *>(dst) = o;
         } else {
-            float *dst = reinterpret_cast<float *>(T.out) + s * T.out_sample_stride + orow;
-            for (int j = 0; j < 8; ++j)
-                if (c0 + j < T.ld) dst[j] = j < nval ? w[j] : 0.f;
+            // a bias, or the ragged end of a row whose padding starts inside this group: values, then zeros
+            for (int j = 0; j < 8; ++j) {
+                if (c0 + j >= t_ld) break;
+                const float v = j < nval ? w[j] : 0.f;
+                if (t_bf16) reinterpret_cast<uint16_t *>(dst)[j] = f2bf(v);
+                else reinterpret_cast<float *>(dst)[j] = v;
+            }
         }
     }
 }
@@ -163,6 +179,8 @@ struct DenseParams {
     int32_t flags;              // BNN_FLAG_RELU, BNN_FLAG_Y_BF16
 };
 
+constexpr int kDenseNoXcdMap = 1 << 20;     // internal flag (BNN_DENSE_XCD=0): plain sample-major block order, for A/B runs
+
 // one LDS-DMA piece, scalar-base form: 64 lanes x 16 B from (base + voff) land at lds + 16 * lane
 __device__ __forceinline__ void dma_piece(const void *base, uint32_t voff, uint32_t lds)
 {
@@ -171,20 +189,29 @@ __device__ __forceinline__ void dma_piece(const void *base, uint32_t voff, uint3
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds) : "memory");
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void k_dense_bf16(const DenseParams p)
+// ROLE split (8 waves): waves 0-3 consume (fragment reads + MFMA + epilogue), waves 4-7 load.  Loader i fills consumer
+// i's private A ring and a quarter of the shared B tile; one s_barrier per 64-k step, met by all eight waves, is the
+// only hand-off: at barrier t the loaders have waited for THEIR pieces of step t (counted vmcnt: step t + 1's stay in
+// flight) and the consumers have finished step t - 1, whose stage the loaders refill right after the barrier with
+// step t + 2.  The DMA issue stream (~5 instructions per 1-KiB piece) thus runs on the SIMD's second wave beside the
+// MFMA stream instead of in front of it (first version, one role: DMA-only 16.6 us, MFMA-only 18.8 us, together 26.8 us).
+// DIAG (BNN_DENSE_DIAG, timing-only builds whose outputs are wrong): 1 = consumers skip reads and MFMAs, 2 = loaders skip the DMA.
+template <int TM, int TN, bool YBF, bool RELU, int DIAG = 0>
+__global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
 {
-    constexpr int NWV = 4;
+    constexpr int NWV = 4;                              // consumer waves = loader waves
     constexpr int WM = 16 * TM, BM = NWV * WM, BN = 16 * TN;
     constexpr int ST = 3;                               // ring stages
-    constexpr int A_PIECES = WM / 8;                    // 1-KiB pieces (8 rows x 128 B) per wave per stage
-    constexpr int B_ROWS = (BN + 31) / 32 * 32;         // padded so that every wave issues the same number of pieces
-    constexpr int B_PIECES = B_ROWS / 8 / NWV;          // per wave per stage
-    constexpr int P = A_PIECES + B_PIECES;              // VMEM ops per wave per stage
+    constexpr int A_PIECES = WM / 8;                    // 1-KiB pieces (8 rows x 128 B) per consumer per stage
+    constexpr int B_TOTAL = BN / 8;                     // pieces of the shared B tile per stage
+    constexpr int B_BASE = B_TOTAL / NWV, B_EXTRA = B_TOTAL % NWV;   // loader i issues B_BASE (+1 if i < B_EXTRA)
     constexpr int A_STAGE = WM * 128;                   // bytes
-    constexpr int B_STAGE = B_ROWS * 128;
+    constexpr int B_STAGE = BN * 128;
     constexpr int A_RING = ST * A_STAGE;
-    static_assert(A_RING >= WM * BN * 4, "the wave's A ring must hold its output tile (epilogue staging)");
+    // epilogue staging: EPI_A 16-row blocks of the wave's output tile fit its A ring at a time
+    constexpr int ESZ = YBF ? 2 : 4;
+    constexpr int EPI_A = (A_RING / (16 * BN * ESZ)) < TM ? (A_RING / (16 * BN * ESZ)) : TM;
+    static_assert(EPI_A >= 1, "the wave's A ring must hold at least 16 output rows (epilogue staging)");
     __shared__ __attribute__((aligned(16))) char lds[NWV * A_RING + ST * B_STAGE];
 
     // ---- block decode: sample -> XCD when the samples fill the 8 XCDs
@@ -192,7 +219,7 @@ __global__ __launch_bounds__(256) void k_dense_bf16(const DenseParams p)
     int s, t;
     {
         const int L = (int)blockIdx.x;
-        if (p.S % 8 == 0) {
+        if (p.S % 8 == 0 && !(p.flags & kDenseNoXcdMap)) {
             const int idx = L >> 3;
             s = (L & 7) + 8 * (idx / per_s);
             t = idx % per_s;
@@ -205,79 +232,93 @@ __global__ __launch_bounds__(256) void k_dense_bf16(const DenseParams p)
     const int m0 = mt * BM, n0 = panel * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fi = lane & 15, fq = lane >> 4;
-
-    char *a_ring = lds + wave * A_RING;
+    const int nk = (p.K + 63) / 64;
     char *b_ring = lds + NWV * A_RING;
-    const uint32_t a_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(a_ring));
-    const uint32_t b_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(b_ring)) + (uint32_t)(wave * B_PIECES) * 1024u;
 
-    // ---- DMA sources.  Lane l writes position l & 7 of row l >> 3 of its piece and therefore fetches chunk
-    // (l & 7) ^ (l >> 3) of that row (the image's XOR swizzle, applied on the source address).
-    const int prow = lane >> 3;
-    const int schunk = (lane & 7) ^ prow;
-    const char *a_base = reinterpret_cast<const char *>(p.A + (int64_t)s * p.a_sample_stride);
-    const char *w_base = reinterpret_cast<const char *>(p.W + (int64_t)s * p.w_sample_stride);
-    uint32_t a_off[A_PIECES], b_off[B_PIECES];
+    if (wave >= NWV) {
+        // =============================== loader ===============================
+        const int lw = wave - NWV;
+        const uint32_t a_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(lds + lw * A_RING));
+        const uint32_t b_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(b_ring));
+        // Lane l writes position l & 7 of row l >> 3 of its piece and therefore fetches chunk (l & 7) ^ (l >> 3) of
+        // that row (the image's XOR swizzle, applied on the source address).
+        const int prow = lane >> 3;
+        const int schunk = (lane & 7) ^ prow;
+        const char *a_base = reinterpret_cast<const char *>(p.A + (int64_t)s * p.a_sample_stride);
+        const char *w_base = reinterpret_cast<const char *>(p.W + (int64_t)s * p.w_sample_stride);
+        uint32_t a_off[A_PIECES], b_off[B_BASE + 1];
 #pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) {
-        int m = m0 + wave * WM + 8 * j + prow;
-        m = m < p.M ? m : p.M - 1;                      // rows >= M: clamped, results never stored
-        a_off[j] = (uint32_t)((int64_t)m * p.lda * 2);
+        for (int j = 0; j < A_PIECES; ++j) {
+            int m = m0 + lw * WM + 8 * j + prow;
+            m = m < p.M ? m : p.M - 1;                  // rows >= M: clamped, results never stored
+            a_off[j] = (uint32_t)((int64_t)m * p.lda * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < B_BASE + 1; ++j) {
+            int n = n0 + (lw + NWV * j) * 8 + prow;     // piece q = lw + 4 j of the tile
+            n = n < p.N ? n : p.N - 1;                  // rows >= N: clamped, results never stored
+            b_off[j] = (uint32_t)((int64_t)n * p.ldw * 2) + 16u * (uint32_t)schunk;
+        }
+        const uint32_t a_colmax = (uint32_t)(p.K * 2 - 16);    // last legal 16-B chunk of an activation row
+        auto run = [&](auto nbp_c) {
+            constexpr int NBP = decltype(nbp_c)::value;
+            constexpr int P = A_PIECES + NBP;           // VMEM ops of this wave per stage
+            auto issue = [&](int kt) {
+                if constexpr (DIAG == 2) return;
+                const int stage = kt % ST;
+                const uint32_t colA0 = (uint32_t)(kt * 128 + 16 * schunk);
+                const uint32_t colA = colA0 < a_colmax ? colA0 : a_colmax;   // k >= K: any finite chunk (the weights are 0 there)
+                const uint32_t colB = (uint32_t)(kt * 128);
+#pragma unroll
+                for (int j = 0; j < A_PIECES; ++j)
+                    dma_piece(a_base, a_off[j] + colA, a_lds + (uint32_t)(stage * A_STAGE + j * 1024));
+#pragma unroll
+                for (int j = 0; j < NBP; ++j)
+                    dma_piece(w_base, b_off[j] + colB, b_lds + (uint32_t)(stage * B_STAGE + (lw + NWV * j) * 1024));
+            };
+            issue(0);
+            if (nk > 1) issue(1);
+            for (int kt = 0; kt < nk; ++kt) {
+                // this wave's pieces of step kt have landed (step kt + 1's P pieces may still be in flight)
+                if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();           // barrier kt: stage kt complete; stage (kt + 2) % 3 = (kt - 1) % 3 is free
+                if (kt + 2 < nk) issue(kt + 2);
+            }
+        };
+        if (lw < B_EXTRA) run(std::integral_constant<int, B_BASE + 1>{});
+        else run(std::integral_constant<int, B_BASE>{});
+        return;
     }
-#pragma unroll
-    for (int j = 0; j < B_PIECES; ++j) {
-        int n = n0 + (wave * B_PIECES + j) * 8 + prow;
-        n = n < p.N ? n : p.N - 1;                      // rows >= N (and the tile's padding rows): clamped
-        b_off[j] = (uint32_t)((int64_t)n * p.ldw * 2) + 16u * (uint32_t)schunk;
-    }
-    const uint32_t a_colmax = (uint32_t)(p.K * 2 - 16);  // last legal 16-B chunk of an activation row
-    auto issue = [&](int kt) {
-        const int stage = kt % ST;
-        const uint32_t colA0 = (uint32_t)(kt * 128 + 16 * schunk);
-        const uint32_t colA = colA0 < a_colmax ? colA0 : a_colmax;       // k >= K: any finite chunk (the weights are 0 there)
-        const uint32_t colB = (uint32_t)(kt * 128);
-#pragma unroll
-        for (int j = 0; j < A_PIECES; ++j)
-            dma_piece(a_base, a_off[j] + colA, a_lds + (uint32_t)(stage * A_STAGE + j * 1024));
-#pragma unroll
-        for (int j = 0; j < B_PIECES; ++j)
-            dma_piece(w_base, b_off[j] + colB, b_lds + (uint32_t)(stage * B_STAGE + j * 1024));
-    };
 
+    // =============================== consumer ===============================
+    const int fi = lane & 15, fq = lane >> 4;
+    char *a_ring = lds + wave * A_RING;
+    __builtin_amdgcn_s_setprio(1);                      // the MFMA stream goes first on its SIMD
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.K + 63) / 64;
-    issue(0);
-    if (nk > 1) issue(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        // this wave's pieces of step kt have landed (step kt + 1's P pieces may still be in flight) ...
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and after the barrier so have the other waves' quarters of B; every wave has also finished reading
-        // step kt - 1, whose stage is the one refilled next
+    // fragment (row 16 x + fi, 32-k half h) sits at  row * 128 + (((4 h + fq) ^ (row & 7)) << 4), and row & 7 = fi & 7:
+    // two lane-constant bases (h = 0, 1) + compile-time offsets (16-row block, stage)
+    const int fbase0 = fi * 128 + (((0 + fq) ^ (fi & 7)) << 4);
+    const int fbase1 = fi * 128 + (((4 + fq) ^ (fi & 7)) << 4);
+    auto step = [&](auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue(kt + 2);
-        const char *As = a_ring + (kt % ST) * A_STAGE;
-        const char *Bs = b_ring + (kt % ST) * B_STAGE;
+        if constexpr (DIAG == 1) return;
+        const char *As = a_ring + stage * A_STAGE;
+        const char *Bs = b_ring + stage * B_STAGE;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            const int fb = h ? fbase1 : fbase0;
             uint4 af[TM], bfr[TN];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int row = b * 16 + fi;
-                bfr[b] = *reinterpret_cast<const uint4 *>(Bs + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4));
-            }
+            for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const uint4 *>(Bs + fb + b * 2048);
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int row = a * 16 + fi;
-                af[a] = *reinterpret_cast<const uint4 *>(As + row * 128 + (((4 * h + fq) ^ (row & 7)) << 4));
-            }
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const uint4 *>(As + fb + a * 2048);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -285,42 +326,56 @@ __global__ __launch_bounds__(256) void k_dense_bf16(const DenseParams p)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
                                                                         __builtin_bit_cast(bf16x8, bfr[b]), acc[a][b], 0, 0, 0);
         }
+    };
+    for (int kt = 0; kt < nk; kt += ST) {
+        step(std::integral_constant<int, 0>{});
+        if (kt + 1 < nk) step(std::integral_constant<int, 1>{});
+        if (kt + 2 < nk) step(std::integral_constant<int, 2>{});
     }
+    __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue: bias, activation, store (accumulator lane (i, q), register r = row 4 q + r, column i of a 16 x 16 block)
-    const bool ybf = (p.flags & BNN_FLAG_Y_BF16) != 0;
-    const bool relu = (p.flags & BNN_FLAG_RELU) != 0;
     const float *bias = p.bias ? p.bias + (int64_t)s * p.bias_sample_stride : nullptr;
-    const int esz = ybf ? 2 : 4;
-    const int64_t ybase = (int64_t)s * p.y_sample_stride * esz;
+    const int64_t ybase = (int64_t)s * p.y_sample_stride * ESZ;
     const int mw = m0 + wave * WM;
-    const bool wide = n0 + BN <= p.N && mw + WM <= p.M && (p.ldy * esz) % 16 == 0 && (n0 * esz) % 16 == 0 &&
+    float bv[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + b * 16 + fi;
+        bv[b] = (bias && n < p.N) ? bias[n] : 0.f;
+    }
+    const bool wide = n0 + BN <= p.N && mw + WM <= p.M && (p.ldy * ESZ) % 16 == 0 && (n0 * ESZ) % 16 == 0 &&
                       ((reinterpret_cast<uintptr_t>(p.Y) + ybase) & 15u) == 0;
     if (wide) {
-        // every wave passed the last barrier after ITS last read of the A ring: the ring is free
+        // this wave's last read of its A ring is behind it (its MFMAs have their operands) and no loader writes it again
         char *T = a_ring;
-        const int pitch = BN * esz;
+        constexpr int pitch = BN * ESZ;
+        constexpr int cpr = pitch / 16;
+        char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)mw * p.ldy + n0) * ESZ;
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const float bv = bias ? bias[n0 + b * 16 + fi] : 0.f;
+        for (int a0 = 0; a0 < TM; a0 += EPI_A) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+            for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[a][b][r] + bv;
-                    if (relu) v = fmaxf(v, 0.f);
-                    char *q = T + (a * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * esz;
-                    if (ybf) *reinterpret_cast<uint16_t *>(q) = f2bf(v);
-                    else *reinterpret_cast<float *>(q) = v;
-                }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's ds_writes before its ds_reads
-        __builtin_amdgcn_wave_barrier();
-        const int cpr = pitch / 16;
-        char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)mw * p.ldy + n0) * esz;
-        for (int c = lane; c < WM * cpr; c += 64) {
-            const int row = c / cpr, cc = c - row * cpr;
-            *reinterpret_cast<uint4 *>(Y8 + (int64_t)row * p.ldy * esz + cc * 16) = *reinterpret_cast<const uint4 *>(T + row * pitch + cc * 16);
+                for (int a = a0; a < a0 + EPI_A && a < TM; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[a][b][r] + bv[b];
+                        if (RELU) v = fmaxf(v, 0.f);
+                        char *q = T + ((a - a0) * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * ESZ;
+                        if (YBF) *reinterpret_cast<uint16_t *>(q) = f2bf(v);
+                        else *reinterpret_cast<float *>(q) = v;
+                    }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's ds_writes before its ds_reads
+            __builtin_amdgcn_wave_barrier();
+            const int nrows = (TM - a0 < EPI_A ? TM - a0 : EPI_A) * 16;
+            for (int c = lane; c < nrows * cpr; c += 64) {
+                const int row = c / cpr, cc = c - row * cpr;
+                *reinterpret_cast<uint4 *>(Y8 + (int64_t)(a0 * 16 + row) * p.ldy * ESZ + cc * 16) =
+                    *reinterpret_cast<const uint4 *>(T + row * pitch + cc * 16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // ... and its ds_reads before the next pass's ds_writes
+            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
@@ -330,16 +385,15 @@ __global__ __launch_bounds__(256) void k_dense_bf16(const DenseParams p)
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + b * 16 + fi;
         if (n >= p.N) continue;
-        const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mw + a * 16 + fq * 4 + r;
                 if (m >= p.M) continue;
-                float v = acc[a][b][r] + bv;
-                if (relu) v = fmaxf(v, 0.f);
-                if (ybf) Yh[(int64_t)m * p.ldy + n] = f2bf(v);
+                float v = acc[a][b][r] + bv[b];
+                if (RELU) v = fmaxf(v, 0.f);
+                if (YBF) Yh[(int64_t)m * p.ldy + n] = f2bf(v);
                 else Yf[(int64_t)m * p.ldy + n] = v;
             }
     }
@@ -438,7 +492,7 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         d.rows = (int32_t)t.rows; d.cols = (int32_t)t.cols; d.ld = (int32_t)t.ld; d.bf16 = t.out_dtype == BNN_BF16;
         d.first_item = (int32_t)items;
         d.rng = make_rng(&t.rng);
-        items += t.rows * ((t.ld + 7) / 8);
+        items += (t.rows * ((t.ld + 7) / 8) + 255) / 256 * 256;     // a workgroup works on one tensor
         if (items > 0x7FFFFF00) { set_error("%s: too many elements for one call", who); return BNN_E_RANGE; }
     }
     L.total_items = (int32_t)items;
@@ -451,7 +505,10 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         }
         grid += L.kl.nblocks;
     }
-    hipLaunchKernelGGL(k_draw_multi, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, L);
+    static const int variant = [] { const char *e = getenv("BNN_DRAW_UNROLL"); return e ? atoi(e) : 1; }();
+    if (variant == 2) hipLaunchKernelGGL(k_draw_multi<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, L);
+    else if (variant == 4) hipLaunchKernelGGL(k_draw_multi<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, L);
+    else hipLaunchKernelGGL(k_draw_multi<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, L);
     return check_launch(who);
 }
 
@@ -489,6 +546,8 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
         return check_launch(who);
     }
     static const int force_tn = [] { const char *e = getenv("BNN_DENSE_TN"); return e ? atoi(e) : 0; }();
+    static const bool no_xcd = [] { const char *e = getenv("BNN_DENSE_XCD"); return e && e[0] == '0'; }();
+    if (no_xcd) p.flags |= kDenseNoXcdMap;
     // tile: 256 rows x 16 TN columns.  TN = 5 (80 columns) divides the BASELINE width 1200 exactly: 2 x 15 x 8 = 240
     // workgroups on 256 CUs; wide layers take 128 columns.
     int tn = (N % 80 == 0 || N < 128) ? 5 : 8;
@@ -498,8 +557,23 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
     p.ntn = (int32_t)((N + bn - 1) / bn);
     const int64_t grid = (int64_t)p.ntm * p.ntn * nsamples;
     if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
-    if (tn == 5) hipLaunchKernelGGL((k_dense_bf16<4, 5>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_dense_bf16<4, 8>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    static const int diag = [] { const char *e = getenv("BNN_DENSE_DIAG"); return e ? atoi(e) : 0; }();
+    const bool relu = (flags & BNN_FLAG_RELU) != 0;
+    const dim3 g((unsigned)grid), blk(512);
+#define BNN_DENSE_LAUNCH(TN_, YBF_, RELU_) \
+    do { \
+        if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<4, TN_, YBF_, RELU_, 1>), g, blk, 0, st, p); \
+        else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<4, TN_, YBF_, RELU_, 2>), g, blk, 0, st, p); \
+        else hipLaunchKernelGGL((k_dense_bf16<4, TN_, YBF_, RELU_>), g, blk, 0, st, p); \
+    } while (0)
+    if (tn == 5) {
+        if (ybf) { if (relu) BNN_DENSE_LAUNCH(5, true, true); else BNN_DENSE_LAUNCH(5, true, false); }
+        else { if (relu) BNN_DENSE_LAUNCH(5, false, true); else BNN_DENSE_LAUNCH(5, false, false); }
+    } else {
+        if (ybf) { if (relu) BNN_DENSE_LAUNCH(8, true, true); else BNN_DENSE_LAUNCH(8, true, false); }
+        else { if (relu) BNN_DENSE_LAUNCH(8, false, true); else BNN_DENSE_LAUNCH(8, false, false); }
+    }
+#undef BNN_DENSE_LAUNCH
     return check_launch(who);
 }
 

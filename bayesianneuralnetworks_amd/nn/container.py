@@ -79,8 +79,16 @@ class BayesianNetworkModule(Module):
 
     def _forward_batched_stacked(self, x, samples, sample0, *args, **kwargs):
         B = x.shape[0]
-        with _mc.McContext(samples, B, sample0):
-            y = self._forward(x, *args, **kwargs)
+        with _mc.McContext(samples, B, sample0) as ctx:
+            drawn = self._draw_plan(ctx)
+            try:
+                y = self._forward(x, *args, **kwargs)
+            finally:
+                for m in drawn:
+                    left = getattr(m, "_predrawn", None)
+                    if left is not None:
+                        left[1].wait()          # a layer `_forward` never reached: join its side-stream draw anyway
+                    m._predrawn = None
         if y.shape[0] == B * samples:
             return y.view(samples, B, *y.shape[1:])
         if y.shape[0] == B:
@@ -88,6 +96,45 @@ class BayesianNetworkModule(Module):
             return y.unsqueeze(0).expand(samples, *y.shape)
         raise RuntimeError("mc_batched: _forward returned %d rows for batch %d x %d samples"
                            % (y.shape[0], B, samples))
+
+    def _draw_plan(self, ctx):
+        """bf16 compute mode: the posteriors of EVERY NormalLinear of the network are drawn for this forward's S samples
+        in ONE launch (ops.draw_layers -> bnn_draw_multi) before `_forward` runs; each layer then finds its drawn
+        weights (consumed on first use: a layer called twice draws again, like the reference's per-call sample(),
+        dense.py:56-58).  Keys are recorded per layer exactly as layer.sample() would.  Returns the layers it drew for."""
+        from .. import ops
+        from . import _settings
+        from .dense import NormalLinear
+        if not ops.DRAW_ONCE_BF16:
+            return []
+        todo = []
+        for m in self.modules():
+            if type(m) is NormalLinear and m.weight.mean.is_cuda and (m.compute or _settings.get_compute()) == "bf16" \
+                    and ops.dense_eligible(m.weight.mean):
+                todo.append(m)
+        if not todo:
+            return []
+        specs = []
+        for m in todo:
+            m.sample(ctx.samples, ctx.sample0)
+            kw, kb = m._keys(ctx.samples)
+            specs.append((m.weight.mean.detach(), m.weight.scale.detach(),
+                          m.bias.mean.detach() if m.bias is not None else None,
+                          m.bias.scale.detach() if m.bias is not None else None, kw, kb))
+        kl = ops._tls.kl_carry
+        if ops.DRAW_SIDE_STREAM and len(specs) > 1:
+            # the first layer's weights on the main stream; the rest (and the KL's first pass) on a side stream, where the
+            # VALU-bound draw runs beside the first layer's draw and DMA / MFMA-bound contraction
+            dev = specs[0][0].device
+            pre = ops.draw_layers(specs[:1], ctx.samples)
+            pre += ops.draw_layers(specs[1:], ctx.samples, kl=kl, stream=ops.side_stream(dev))
+        else:
+            pre = ops.draw_layers(specs, ctx.samples, kl=kl)
+        if kl is not None and kl.launched:
+            ops._tls.kl_carry = None
+        for m, p_ in zip(todo, pre):
+            m._predrawn = (ctx, p_)
+        return todo
 
     def forward_stacked(self, x, samples=None, sample0=0, *args, **kwargs):
         """(S, B, ...) tensor of all MC outputs (batched path when enabled)."""

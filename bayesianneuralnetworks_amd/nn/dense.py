@@ -126,6 +126,13 @@ class NormalLinear(_NormalSampling, BayesianLinear):
             return torch.relu(y) if self.activation == 'relu' else y
         if x.dim() == 1:
             return self.forward(x.unsqueeze(0), sample).squeeze(0)
+        # weights already drawn for this forward by the network's draw plan (container._draw_plan)?  Consumed on use.
+        predrawn = None
+        pd = getattr(self, "_predrawn", None)
+        if pd is not None:
+            self._predrawn = None
+            if sample and pd[0] is _mc.current():
+                predrawn, sample = pd[1], False
         S, _, shared, per = self._mc_plan(x, sample)
         lead = x.shape[1:-1]
         K = x.shape[-1]
@@ -138,7 +145,7 @@ class NormalLinear(_NormalSampling, BayesianLinear):
                                    self.bias.mean if self.bias is not None else None,
                                    self.bias.scale if self.bias is not None else None,
                                    keys[0], keys[1], shared, mode, relu=self.activation == 'relu',
-                                   out_dtype=odt)
+                                   out_dtype=odt, predrawn=predrawn if mode == "bf16" else None)
         else:
             # weights were set explicitly (parity mode / user-assigned .sampled)
             w, b = self.sampled

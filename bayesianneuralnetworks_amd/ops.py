@@ -8,6 +8,7 @@ torch.bmm / torch's conv backward on the GPU (library GEMMs on already-drawn wei
 Every function here requires CUDA (HIP) tensors and raises BnnHipError otherwise.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -130,12 +131,152 @@ def sample_affine_philox(mu, rho, key):
     return _SampleAffinePhilox.apply(mu.contiguous(), rho.contiguous(), key)
 
 
+# --------------------------------------------------------------------------- draw-once path (bf16 compute mode)
+def _pad64(k):
+    return (k + 63) // 64 * 64
+
+
+def dense_eligible(mu_w):
+    """The draw-once path takes a (N, K) posterior whose rows are whole 8-column groups and 16-B aligned."""
+    return mu_w.dim() == 2 and mu_w.shape[1] % 8 == 0 and mu_w.data_ptr() % 16 == 0
+
+
+class Predrawn:
+    """The drawn weights of one layer for one forward: w (S, N, Kp) bf16 zero-padded to Kp = roundup(K, 64),
+    b (S, N) fp32 or None, and the DrawKeys they were drawn with.  `ready`: the side stream the draw was launched on
+    (the consumer's stream waits for it before the contraction), or None."""
+    __slots__ = ("w", "b", "key_w", "key_b", "ready")
+
+    def __init__(self, w, b, key_w, key_b, ready=None):
+        self.w, self.b, self.key_w, self.key_b, self.ready = w, b, key_w, key_b, ready
+
+    def wait(self):
+        """Make the current stream wait for the draw (once: later consumers of the same side-stream launch are ordered
+        behind this one on the same stream)."""
+        if self.ready is not None:
+            torch.cuda.current_stream(self.w.device).wait_stream(self.ready)
+            self.ready = None
+
+
+_side_streams = {}
+
+
+def side_stream(device):
+    """One extra stream per device for work that runs BESIDE the main stream's launches (draw of the later layers under the
+    first layers' contractions: the draw is VALU-bound, the dense GEMM DMA / MFMA-bound, and their workgroups fit a CU
+    together)."""
+    key = (device.type, device.index)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device)
+        _side_streams[key] = st
+    return st
+
+
+def draw_layers(layers, nsamples, kl=None, stream=None):
+    """ONE launch (bnn_draw_multi) draws the weights and biases of every (mu_w, rho_w, mu_b, rho_b, key_w, key_b) in
+    `layers` for `nsamples` MC samples -> list of Predrawn.  kl (a KlDeferred from kl_normal_begin(carry=True)): the
+    launch also carries that KL's first pass.  At most 4 layers (8 tensors) per launch; more are split.
+    stream: launch on that side stream (forked from the current one here; consumers join through Predrawn.wait())."""
+    out = []
+    lib = _lib.load()
+    dev = layers[0][0].device
+    cur = torch.cuda.current_stream(dev)
+    if stream is not None:
+        stream.wait_stream(cur)                     # fork: the draw is ordered behind everything already on the main stream
+    launch_stream = stream if stream is not None else cur
+    sp = _lib.stream_ptr(dev)
+    sp.value = launch_stream.cuda_stream
+    for i0 in range(0, len(layers), 4):
+        group = layers[i0:i0 + 4]
+        arr = (_lib.DrawTensor * (2 * len(group)))()
+        n = 0
+        keep = []
+        for mu_w, rho_w, mu_b, rho_b, key_w, key_b in group:
+            require_cuda_f32(mu_w, "weight.mean")
+            require_cuda_f32(rho_w, "weight.scale")
+            N, K = mu_w.shape
+            kp = _pad64(K)
+            w = torch.empty((nsamples, N, kp), dtype=torch.bfloat16, device=dev)
+            t = arr[n]
+            t.mu, t.rho, t.rows, t.cols = mu_w.data_ptr(), rho_w.data_ptr(), N, K
+            t.out, t.ld, t.out_sample_stride, t.out_dtype = w.data_ptr(), kp, N * kp, _lib.BF16
+            t.rng = _rng_struct(key_w, dev)
+            n += 1
+            b = None
+            if mu_b is not None:
+                require_cuda_f32(mu_b, "bias.mean")
+                require_cuda_f32(rho_b, "bias.scale")
+                b = torch.empty((nsamples, N), dtype=torch.float32, device=dev)
+                t = arr[n]
+                t.mu, t.rho, t.rows, t.cols = mu_b.data_ptr(), rho_b.data_ptr(), 1, N
+                t.out, t.ld, t.out_sample_stride, t.out_dtype = b.data_ptr(), N, N, _lib.F32
+                t.rng = _rng_struct(key_b, dev)
+                n += 1
+            keep.append((mu_w, rho_w, mu_b, rho_b))
+            out.append(Predrawn(w, b, key_w, key_b, ready=stream))
+        carried = False
+        if kl is not None and not kl.launched and i0 == 0 and kl.out.device == dev:
+            rc = lib.bnn_draw_multi(arr, n, nsamples, kl.arr, kl.T, ptr(kl.ws), sp)
+            if rc == 0:
+                kl.launched = carried = True
+            elif rc != _lib.E_UNSUPPORTED:
+                check(rc, "bnn_draw_multi")
+        if not carried:
+            check(lib.bnn_draw_multi(arr, n, nsamples, None, 0, None, sp), "bnn_draw_multi")
+    return out
+
+
+def rows_regular(t, K):
+    """A (M, K) or (S, M, K) bf16 activation whose rows the dense kernel can read in place: unit element stride, one row
+    pitch (>= K, whole 16-B chunks), samples M rows apart -- e.g. the 128-B-aligned rows _dense_raw itself writes."""
+    if t.dtype != torch.bfloat16 or t.dim() not in (2, 3) or t.shape[-1] != K or t.stride(-1) != 1:
+        return False
+    ld = t.stride(-2) if t.shape[-2] > 1 else max(K, t.stride(-2))
+    if ld < K or ld % 8 != 0 or t.data_ptr() % 16 != 0:
+        return False
+    return t.dim() == 2 or t.shape[0] == 1 or t.stride(0) == t.shape[1] * ld
+
+
+def _dense_raw(x2, x_sample_stride, M, pre, K, relu, out_dtype, ldx=None, pad_rows=False):
+    """y (S, M, N) = act(x . w_s^T + b_s) on Predrawn weights (bnn_dense_forward); x bf16 with row pitch ldx.
+    pad_rows (bf16 hidden activations): the rows of y are written 128 B apart-aligned (pitch roundup(N, 64)) and y is
+    returned as a view of that buffer -- the next layer's LDS-DMA then reads whole cache lines (layer 2 of the BASELINE
+    net: 19.6 -> 17.0 us)."""
+    S, N, kp = pre.w.shape
+    ldx = K if ldx is None else ldx
+    ldy = _pad64(N) if (pad_rows and out_dtype == torch.bfloat16) else N
+    ybuf = torch.empty((S, M, ldy), dtype=out_dtype, device=x2.device)
+    flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_Y_BF16 if out_dtype == torch.bfloat16 else 0)
+    check(_lib.load().bnn_dense_forward(ptr(x2), x_sample_stride, ldx, ptr(pre.w), N * kp, kp,
+                                         ptr(pre.b), N if pre.b is not None else 0, ptr(ybuf), M * ldy, ldy, M, N, K, S, flags,
+                                         stream_ptr(x2.device)), "bnn_dense_forward")
+    return ybuf if ldy == N else ybuf[:, :, :N]
+
+
 # --------------------------------------------------------------------------- K2 linear
 def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, compute, relu=False,
-                        out_dtype=torch.float32):
+                        out_dtype=torch.float32, predrawn=None, pad_rows=False):
     N, K = mu_w.shape
     S = key_w.nsamples
     _lib.ensure_workspace(x2.device)
+    if compute == _lib.COMPUTE_BF16 and DRAW_ONCE_BF16 and dense_eligible(mu_w) and M > 0:
+        # bf16 compute mode: the layer's weights are drawn ONCE for the S samples (K1, one launch -- or already drawn
+        # for this forward by the network's draw plan, `predrawn`) and contracted by the dense MFMA GEMM (csrc/bnn_dense.hip).
+        # Same DrawKeys -> the same weights as the fused kernel, bit for bit; the backward re-creates them as always.
+        pre = predrawn
+        if pre is None:
+            pre = draw_layers([(mu_w, rho_w, mu_b, rho_b, key_w, key_b)], S, kl=_tls.kl_carry)[0]
+            if _tls.kl_carry is not None and _tls.kl_carry.launched:
+                _tls.kl_carry = None
+        pre.wait()
+        if x2.dtype == torch.bfloat16 and rows_regular(x2, K):
+            ldx = x2.stride(-2) if M > 1 else K
+            xs = 0 if x_sample_stride == 0 else M * ldx
+            return _dense_raw(x2, xs, M, pre, K, relu, out_dtype, ldx=ldx, pad_rows=pad_rows)
+        xb = x2.contiguous().to(torch.bfloat16)        # (the fused kernel rounds its A operand the same way)
+        return _dense_raw(xb, x_sample_stride, M, pre, K, relu, out_dtype, pad_rows=pad_rows)
+    x2 = x2.contiguous()
     y = torch.empty((S, M, N), dtype=out_dtype, device=x2.device)
     rw = _rng_struct(key_w, x2.device)
     rb = _rng_struct(key_b, x2.device) if mu_b is not None else None
@@ -183,6 +324,11 @@ class _ThreadState(threading.local):
 _tls = _ThreadState()
 # from this many rows per sample on, a sampled linear layer draws its weights once (K1) instead of in the GEMM
 DRAW_ONCE_MIN_ROWS = 2048
+# bf16 compute mode: draw once + dense GEMM at every batch size (False: the round-1 fused kernel, kept for A/B runs)
+DRAW_ONCE_BF16 = True
+# BNN_DRAW_SIDE=1: a network draw plan launches the layers after the first on a side stream, beside the first layer draw + contraction
+# (measured on the BASELINE step: SLOWER, 0.0832 vs 0.0749 ms -- the cross-queue dependency costs more than the overlap hides; off)
+DRAW_SIDE_STREAM = os.environ.get("BNN_DRAW_SIDE", "0") == "1"
 
 
 def _bf(t):
@@ -295,10 +441,14 @@ class _SampledLinear(torch.autograd.Function):
     into its epilogue (csrc/bnn_linear_bwd.hip)."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute, relu, out_dtype):
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute, relu, out_dtype, predrawn=None):
         # x: (M, K) shared by all samples, or (S, M, K), fp32 or (bf16 compute mode) bf16;
         # relu: max(., 0) fused in the epilogue; out_dtype: fp32, or bf16 for a hidden activation
-        require_cuda_act(x, "x")
+        # x may be a row-padded view (rows_regular) on the inference path; whatever the backward saves is contiguous
+        needs_grad = any(ctx.needs_input_grad[:5])
+        if needs_grad or not (x.dtype == torch.bfloat16 and rows_regular(x, x.shape[-1])):
+            x = x.contiguous()
+        require_cuda_act(x, "x", contiguous=False)
         if (x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16) and compute != _lib.COMPUTE_BF16:
             raise BnnHipError("bf16 activations need compute mode 'bf16'")
         for t, n in ((mu_w, "weight.mean"), (rho_w, "weight.scale")):
@@ -311,7 +461,7 @@ class _SampledLinear(torch.autograd.Function):
         if K != mu_w.shape[1]:
             raise BnnHipError("linear: input has %d features, weight expects %d" % (K, mu_w.shape[1]))
         y = _linear_sampled_raw(x, 0 if shared_x else M * K, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b,
-                                compute, relu, out_dtype)
+                                compute, relu, out_dtype, predrawn, pad_rows=not needs_grad)
         ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None, y if relu else None, mu_b)
         ctx.key_w, ctx.key_b, ctx.shared_x, ctx.compute = key_w, key_b, shared_x, compute
         return y
@@ -354,7 +504,7 @@ class _SampledLinear(torch.autograd.Function):
                 ctypes.byref(rw), ctypes.byref(rb) if rb is not None else None,
                 ctypes.byref(kl) if kl is not None else None, flags, 0, stream_ptr(dev))
             if rc == 0:
-                return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None
+                return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None, None
             if rc not in (_lib.E_UNSUPPORTED, _lib.E_ALIGN):
                 check(rc, "bnn_linear_backward_narrow_sampled")
             # not applicable here (workspace, alignment): the general kernels below; hand the KL entries back
@@ -403,15 +553,15 @@ class _SampledLinear(torch.autograd.Function):
         elif need_b:
             gb = _colsum_raw(gy)                                           # (S, N)
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
-        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None, None
 
 
 def linear_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute="f32", relu=False,
-                   out_dtype=torch.float32):
-    return _SampledLinear.apply(x.contiguous(), mu_w.contiguous(), rho_w.contiguous(),
+                   out_dtype=torch.float32, predrawn=None):
+    return _SampledLinear.apply(x, mu_w.contiguous(), rho_w.contiguous(),
                                 None if mu_b is None else mu_b.contiguous(),
                                 None if rho_b is None else rho_b.contiguous(),
-                                key_w, key_b, shared_x, _compute_code(compute), bool(relu), out_dtype)
+                                key_w, key_b, shared_x, _compute_code(compute), bool(relu), out_dtype, predrawn)
 
 
 class _PlainLinear(torch.autograd.Function):

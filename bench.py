@@ -70,6 +70,18 @@ def posteriors(seed=0):
     return out
 
 
+def resident_input(x, mode):
+    """The synthetic batch as it sits in HBM when the timed region starts.  bf16 mode: bf16 (the first layer would round
+    its A operand to bf16 anyway -- identical results, half the input stream) with 128-B aligned rows (row pitch 832 =
+    roundup(784, 64) elements: the dense kernel's LDS-DMA then reads whole cache lines); fp32 mode: fp32, dense."""
+    if mode != "bf16":
+        return x
+    K = x.shape[1]
+    buf = torch.zeros(x.shape[0], (K + 63) // 64 * 64, dtype=torch.bfloat16, device=x.device)
+    buf[:, :K] = x
+    return buf[:, :K]
+
+
 def build_net(dev, post):
     from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule
 
@@ -394,7 +406,10 @@ def kernel_roofline(net, x, mode, dev, iters=50):
     layer = net.layers[2]
     h = torch.randn(SAMPLES * BATCH, DIMS[1], device=dev).relu_()
     if mode == "bf16":
-        h = h.bfloat16()          # the hidden activation the step really feeds this layer
+        # the hidden activation the step really feeds this layer: bf16, 128-B aligned rows (what layer 1's epilogue writes)
+        hb = torch.zeros(SAMPLES * BATCH, (DIMS[1] + 63) // 64 * 64, dtype=torch.bfloat16, device=dev)
+        hb[:, :DIMS[1]] = h
+        h = hb[:, :DIMS[1]]
     layer.compute = mode
     with torch.no_grad(), _mc.McContext(SAMPLES, BATCH, 0):
         ms = _time_launches(lambda: layer(h), dev, iters)
@@ -614,7 +629,7 @@ def main(argv=None):
         bnn.set_compute(mode)
         # bf16 mode: the synthetic batch is resident in HBM as bf16 (the first layer would round its
         # A operand to bf16 anyway -- identical results, half the input stream); fp32 mode: fp32.
-        x_in = x.bfloat16() if mode == "bf16" else x
+        x_in = resident_input(x, mode)
         if strong:
             s0, cnt = bd.shard_samples(SAMPLES, rank, world)
             step = Step(net, x_in, rank, world, not args.no_graph, samples=cnt, sample0=s0, total_samples=SAMPLES)
@@ -638,7 +653,7 @@ def main(argv=None):
     if args.mode == "train" or world == 1:
         tnet = build_net(dev, post)
         tsteps = args.steps if args.mode == "train" else max(10, args.steps // 4)
-        tstep = TrainStep(tnet, x.bfloat16() if args.dtype == "bf16" else x, rank, world, not args.no_graph)
+        tstep = TrainStep(tnet, x.bfloat16() if args.dtype == "bf16" else x, rank, world, not args.no_graph)   # (dense rows: autograd saves x)
         dt = time_steps(tstep, tsteps, args.warmup, world, dev)
         train = (world * SAMPLES * tsteps / dt, dt / tsteps * 1e3, tsteps, float(tstep.loss))
         del tstep, tnet

@@ -201,6 +201,44 @@ int bnn_linear_forward_sampled_kl(const void *x, int64_t x_sample_stride, int64_
                                   int64_t M, int64_t N, int64_t K, int nsamples, const bnn_rng_t *rng_w,
                                   const bnn_rng_t *rng_b, int compute, int flags,
                                   const bnn_kl_tensor_t *tensors, int ntensors, void *kl_workspace, void *stream);
+/* ---- draw-once path of the sampled linear layer (bf16 compute mode) ---------------------------------------
+ * The same layer in two launches instead of one fused one: every posterior tensor of a forward is drawn ONCE
+ * (all S MC samples, sigma computed once per weight) by bnn_draw_multi, then bnn_dense_forward contracts on the
+ * drawn weights -- a dense MFMA GEMM with both operands arriving by LDS-DMA.  Same DrawKey -> the same draws as
+ * the fused kernel and as bnn_sample_affine_philox, bit for bit (one device function).  On MI355X this is the
+ * faster form at the BASELINE shapes: inside the GEMM the draw's ~150 VALU issue slots per 4 weights share each
+ * SIMD's issue port with the MFMAs and pace the kernel through an LDS hand-off.
+ *
+ * One posterior tensor to draw (host struct, read at call time).
+ * replaces  WeightNormal.sample  pytorch_bayesian/nn/core.py:44-45, called weight-then-bias by
+ *           NormalLinear.sample  pytorch_bayesian/nn/dense.py:46-54, once per MC sample by the loop at
+ *           pytorch_bayesian/nn/container.py:36-37 */
+typedef struct bnn_draw_tensor {
+    const float *mu;
+    const float *rho;
+    int64_t rows, cols;         /* posterior shape (N, K); a bias is (1, N).  rows > 1 needs cols % 4 == 0 */
+    void *out;                  /* draw s at out + s * out_sample_stride elements: `rows` rows of `ld` elements */
+    int64_t ld;                 /* >= cols (% 8 == 0 when rows > 1); columns cols .. ld - 1 are written as ZEROS */
+    int64_t out_sample_stride;  /* elements */
+    int out_dtype;              /* BNN_F32 or BNN_BF16 */
+    bnn_rng_t rng;
+} bnn_draw_tensor_t;
+/* Draws <= 8 tensors x nsamples MC samples in ONE launch.  kl_tensors != NULL: the launch also carries the first
+ * pass of that model's KL (as bnn_linear_forward_sampled_kl does; same eligibility, same values) -- finish it with
+ * bnn_mc_sum_kl; BNN_E_UNSUPPORTED (nothing launched) when the KL is not eligible. */
+int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
+                   const bnn_kl_tensor_t *kl_tensors, int kl_ntensors, void *kl_workspace, void *stream);
+/* y[s] = act(x[s] . w[s]^T + b[s]) on drawn weights: x (S or shared: x_sample_stride = 0) x M x ldx bf16,
+ * w S x N x ldw bf16 with every row ZERO beyond K up to ldw >= roundup(K, 64) (what bnn_draw_multi writes),
+ * b S x N fp32 or NULL, y fp32 or (BNN_FLAG_Y_BF16) bf16; BNN_FLAG_RELU.  K % 8 == 0, 16-B aligned rows.
+ * N <= 16 (a classifier head) runs a K-split kernel without LDS staging.  fp32 accumulate (bf16 MFMA).
+ * replaces  F.linear(x, *self.sampled)  pytorch_bayesian/nn/dense.py:60 */
+int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
+                      const void *w, int64_t w_sample_stride, int64_t ldw,
+                      const float *b, int64_t b_sample_stride,
+                      void *y, int64_t y_sample_stride, int64_t ldy,
+                      int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream);
+
 /* Same contraction with the weights given (F.linear(x, w, b), dense.py:60):
  * w[s] = w + s * w_sample_stride, b[s] = b + s * b_sample_stride (b may be NULL). */
 int bnn_linear_forward(const float *x, int64_t x_sample_stride, int64_t ldx,

@@ -71,7 +71,7 @@ def test_timed_graph_replays_match_oracle(mode):
     h = net.layers[2].register_forward_hook(hook)
     try:
         n0 = lib.bnn_launch_count()
-        step = bench.Step(net, x.bfloat16() if mode == "bf16" else x, 0, 1, True)
+        step = bench.Step(net, bench.resident_input(x, mode), 0, 1, True)
         assert step.graph is not None and lib.bnn_launch_count() > n0
         prev = None
         for k in range(3):

@@ -1,0 +1,256 @@
+"""GPU parity of the draw-once path (csrc/bnn_dense.hip): bnn_draw_multi and bnn_dense_forward through the C-ABI
+against the CPU oracle on the same Philox draws, and against the fused kernel / the standalone sampler.
+
+bf16 compute mode: the oracle is fed what the MFMA is fed (bf16-rounded activations and drawn weights, fp32 bias) and
+accumulates in double; the kernel accumulates the exact bf16 products in fp32 -> 1e-5 of the output scale
+(conftest.allclose_scaled), the same bar as the fp32 path."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import allclose_scaled
+import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available()
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd import _lib, ops
+    from oracle import oracle as orc
+    return dict(bnn=bnn, lib=_lib.load(), _lib=_lib, ops=ops, orc=orc, dev=torch.device("cuda:0"))
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+def _post(shape, seed, dev, bias=True):
+    gen = torch.Generator().manual_seed(seed)
+    mw, rw, mb, rb = seeded.posterior(gen, shape, bias)
+    return [t.to(dev) if t is not None else None for t in (mw, rw, mb, rb)]
+
+
+@pytest.mark.parametrize("shape", [(1200, 784), (10, 1200), (64, 48), (7, 16), (80, 264)])
+@pytest.mark.parametrize("S", [1, 8])
+def test_draw_multi_equals_standalone_sampler_and_oracle(env, shape, S):
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    ops, orc, dev = env["ops"], env["orc"], env["dev"]
+    mw, rw, mb, rb = _post(shape, 5, dev)
+    kw, kb = DrawKey(99, 11, 2, S, 7), DrawKey(99, 12, 2, S, 7)
+    n0 = env["lib"].bnn_launch_count()
+    pre = ops.draw_layers([(mw, rw, mb, rb, kw, kb)], S)[0]
+    assert env["lib"].bnn_launch_count() == n0 + 1            # weight AND bias, all samples: one launch
+    Nn, K = shape
+    kp = (K + 63) // 64 * 64
+    assert pre.w.shape == (S, Nn, kp) and pre.b.shape == (S, Nn)
+    # (a) bit-identical to K1 (same device function, same key), zero padding
+    w1 = ops._sample_affine_philox_raw(mw, rw, kw, out_dtype=torch.bfloat16)
+    assert torch.equal(pre.w[:, :, :K], w1)
+    assert (pre.w[:, :, K:] == 0).all()
+    assert torch.equal(pre.b, ops._sample_affine_philox_raw(mb, rb, kb))
+    # (b) the oracle's draw, rounded to bf16: at most one bf16 ulp apart (the eps twin agrees to ~1e-6)
+    for s in range(S):
+        ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, shape)
+        want = orc.sample_affine(N(mw), N(rw), ew)
+        got = N(pre.w[s, :, :K])
+        assert (np.abs(got - want) <= np.abs(want) * 2.0 ** -8 + 1e-6).all()
+        eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, (Nn,))
+        assert np.allclose(N(pre.b[s]), orc.sample_affine(N(mb), N(rb), eb), atol=1e-5, rtol=1e-5)
+
+
+def test_draw_multi_many_layers_and_kl_carry(env):
+    """Three layers (6 tensors) + the KL first pass in ONE launch; the KL finished by mc_mean equals kl_normal's."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    ops, dev = env["ops"], env["dev"]
+    posts = [_post(sh, 20 + i, dev) for i, sh in enumerate([(96, 64), (40, 96), (10, 40)])]
+    layers, mus, rhos = [], [], []
+    for i, (mw, rw, mb, rb) in enumerate(posts):
+        layers.append((mw, rw, mb, rb, DrawKey(5, 2 * i + 1, 0, 4, 3), DrawKey(5, 2 * i + 2, 0, 4, 3)))
+        mus += [mw, mb]
+        rhos += [rw, rb]
+    priors = [(0.0, 0.1)] * 6
+    ref = ops.kl_normal(mus, rhos, priors, 2.0)
+    h = ops.kl_normal_begin(mus, rhos, priors, 2.0, carry=True)
+    n0 = env["lib"].bnn_launch_count()
+    pre = ops.draw_layers(layers, 4, kl=h)
+    assert env["lib"].bnn_launch_count() == n0 + 1 and h.launched
+    ops._tls.kl_carry = None
+    ys = torch.zeros(4, 8, device=dev)
+    ops.mc_mean(ys, kl=h)
+    assert torch.equal(h.out, ref)
+    for (mw, rw, mb, rb, kw, kb), p_ in zip(layers, pre):
+        assert torch.equal(p_.w[:, :, :mw.shape[1]], ops._sample_affine_philox_raw(mw, rw, kw, out_dtype=torch.bfloat16))
+        assert torch.equal(p_.b, ops._sample_affine_philox_raw(mb, rb, kb))
+
+
+DENSE_SHAPES = [  # S, M, N, K, shared_x, relu, y_bf16
+    (2, 17, 80, 72, False, False, False),
+    (3, 130, 96, 264, False, True, False),        # ragged rows and columns, K tail (264 = 4 x 64 + 8)
+    (2, 300, 200, 128, True, False, True),
+    (1, 256, 160, 64, False, False, False),
+    (8, 512, 1200, 784, True, True, True),        # BASELINE layer 1 (shared input, ReLU, bf16 hidden activation)
+    (8, 512, 1200, 1200, False, True, True),      # BASELINE layer 2
+    (8, 512, 10, 1200, False, False, False),      # BASELINE head
+    (2, 33, 5, 40, False, False, False),
+    (3, 40, 16, 2048, True, True, False),
+    (1, 1, 10, 8, False, False, False),
+    (2, 260, 256, 320, False, False, False),      # 128-column tiles
+]
+
+
+@pytest.mark.parametrize("S,M,Nn,K,shared,relu,ybf", DENSE_SHAPES)
+def test_dense_forward_vs_oracle(env, S, M, Nn, K, shared, relu, ybf):
+    """bnn_dense_forward (through the C-ABI) on given bf16 operands against the oracle's F.linear (double accumulate)."""
+    lib, _lib, orc, dev = env["lib"], env["_lib"], env["orc"], env["dev"]
+    g = torch.Generator().manual_seed(S * 1000 + M + Nn + K)
+    kp = (K + 63) // 64 * 64
+    x = torch.randn((M, K) if shared else (S, M, K), generator=g).bfloat16()
+    w = torch.zeros(S, Nn, kp, dtype=torch.bfloat16)
+    w[:, :, :K] = (torch.randn(S, Nn, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(S, Nn, generator=g) * 0.1
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    y = torch.full((S, M, Nn), float("nan"), dtype=torch.bfloat16 if ybf else torch.float32, device=dev)
+    flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_Y_BF16 if ybf else 0)
+    rc = lib.bnn_dense_forward(_lib.ptr(xd), 0 if shared else M * K, K, _lib.ptr(wd), Nn * kp, kp, _lib.ptr(bd), Nn,
+                               _lib.ptr(y), M * Nn, Nn, M, Nn, K, S, flags, _lib.stream_ptr(dev))
+    assert rc == 0, lib.bnn_last_error()
+    torch.cuda.synchronize()
+    got = N(y)
+    xf, wf = x.float().numpy(), w.float().numpy()[:, :, :K]
+    for s in range(S):
+        xs = xf if shared else xf[s]
+        if M * Nn * K <= 50_000_000:
+            want = orc.linear(xs, wf[s], b[s].numpy())
+        else:
+            # orc_linear's arithmetic (exact products, double accumulation, one rounding) evaluated by BLAS
+            want = (xs.astype(np.float64) @ wf[s].astype(np.float64).T + b[s].numpy().astype(np.float64)).astype(np.float32)
+        if relu:
+            want = np.maximum(want, 0)
+        if ybf:
+            assert (np.abs(got[s] - want) <= np.abs(want) * 2.0 ** -8 + 1e-5 * max(1.0, float(np.sqrt((want ** 2).mean())))).all()
+        else:
+            assert allclose_scaled(got[s], want), np.abs(got[s] - want).max()
+
+
+def test_dense_forward_rejects_unpadded_weights_and_bad_alignment(env):
+    lib, _lib, dev = env["lib"], env["_lib"], env["dev"]
+    x = torch.zeros(4, 72, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(1, 16, 72, dtype=torch.bfloat16, device=dev)            # ldw = 72 < roundup(72, 64) = 128
+    y = torch.zeros(1, 4, 16, device=dev)
+    n0 = lib.bnn_launch_count()
+    assert lib.bnn_dense_forward(_lib.ptr(x), 0, 72, _lib.ptr(w), 16 * 72, 72, None, 0, _lib.ptr(y), 64, 16, 4, 16, 72, 1, 0,
+                                 _lib.stream_ptr(dev)) == _lib.E_UNSUPPORTED
+    assert lib.bnn_dense_forward(_lib.ptr(x), 0, 72, _lib.ptr(w), 16 * 72, 72, None, 0, _lib.ptr(y), 64, 16, 4, 16, 70, 1, 0,
+                                 _lib.stream_ptr(dev)) < 0
+    assert lib.bnn_launch_count() == n0
+
+
+@pytest.mark.parametrize("dims,B,S", [((784, 1200, 1200, 10), 512, 8), ((96, 200, 120, 10), 40, 4), ((64, 80, 16), 33, 2)])
+def test_layer_on_draw_once_path_equals_fused_kernel_and_oracle(env, dims, B, S):
+    """The Module path in bf16 mode (draw plan -> one draw launch for the whole net + dense GEMMs) against (a) the same
+    net on the round-1 fused kernels (same keys; same bf16 products, another fp32 summation order) and (b) the oracle."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule, fuse_activations
+    ops, orc, dev = env["ops"], env["orc"], env["dev"]
+    posts = seeded.mlp_posteriors(dims, seed=3)
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(dims[0], dims[-1], S)
+            mods = []
+            for j, (mw, rw, mb, rb) in enumerate(posts):
+                L = NormalLinear(mw.shape[1], mw.shape[0])
+                with torch.no_grad():
+                    L.weight.mean.copy_(mw); L.weight.scale.copy_(rw); L.bias.mean.copy_(mb); L.bias.scale.copy_(rb)
+                mods.append(L)
+                if j < len(posts) - 1:
+                    mods.append(torch.nn.ReLU())
+            self.layers = torch.nn.Sequential(*mods)
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    net = Net().to(dev)
+    net.mc_batched = True
+    fuse_activations(net, bf16_activations=True)
+    x = torch.randn(B, dims[0], generator=torch.Generator().manual_seed(9)).to(dev)
+    bnn.set_compute("bf16")
+    try:
+        bnn.manual_seed(31)
+        n0 = env["lib"].bnn_launch_count()
+        with torch.no_grad():
+            y_new = net.forward_stacked(x.bfloat16(), S)
+        nl = len(posts)
+        assert env["lib"].bnn_launch_count() == n0 + 1 + nl       # ONE draw launch + one contraction per layer
+        keys = [(L.weight.draw_key, L.bias.draw_key) for L in net.layers if hasattr(L, "weight")]
+        ops.DRAW_ONCE_BF16 = False
+        bnn.manual_seed(31)
+        with torch.no_grad():
+            y_old = net.forward_stacked(x.bfloat16(), S)
+        assert [(a.epoch_host, a.stream) for a, _ in keys] == [(L.weight.draw_key.epoch_host, L.weight.draw_key.stream)
+                                                                for L in net.layers if hasattr(L, "weight")]
+    finally:
+        ops.DRAW_ONCE_BF16 = True
+        bnn.set_compute("f32")
+    a, b = N(y_new), N(y_old)
+    rms = float(np.sqrt((b ** 2).mean()))
+    # hidden activations are stored in bf16: a sum that differs in the last fp32 bit can round to the neighbouring bf16
+    # value on one path -- one bf16 ulp of a few hidden units, ~1e-3 of the output scale after the next layer
+    assert np.abs(a - b).max() <= 2.0 ** -8 * max(1.0, rms), (np.abs(a - b).max(), rms)
+    # (b) oracle, 48 rows, bf16-rounded operands
+    rows = min(B, 48)
+    h0 = orc.bf16_round(N(x[:rows]))
+    for s in range(S):
+        h = h0
+        for li, ((mw, rw, mb, rb), (kw, kb)) in enumerate(zip(posts, keys)):
+            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, tuple(mw.shape))
+            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, tuple(mb.shape))
+            h = orc.linear(h, orc.bf16_round(orc.sample_affine(mw.numpy(), rw.numpy(), ew)), orc.sample_affine(mb.numpy(), rb.numpy(), eb))
+            if li < len(posts) - 1:
+                h = orc.bf16_round(np.maximum(h, 0))
+        r = float(np.sqrt((h ** 2).mean()))
+        assert np.abs(a[s, :rows] - h).max() <= 2.0 ** -7 * max(1.0, r), (np.abs(a[s, :rows] - h).max(), r)
+
+
+def test_draw_plan_is_consumed_once_and_matches_per_layer_draws(env):
+    """Bitwise: the network-level draw plan (one launch for all layers) == every layer drawing for itself."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule
+    from bayesianneuralnetworks_amd import _mc
+    dev = env["dev"]
+    torch.manual_seed(4)
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(64, 10, 4)
+            self.layers = torch.nn.Sequential(NormalLinear(64, 80), torch.nn.ReLU(), NormalLinear(80, 10))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    net = Net().to(dev)
+    net.mc_batched = True
+    x = torch.randn(24, 64, device=dev)
+    bnn.set_compute("bf16")
+    try:
+        bnn.manual_seed(8)
+        with torch.no_grad():
+            y_plan = net.forward_stacked(x, 4)
+        assert all(getattr(m, "_predrawn", None) is None for m in net.modules())      # nothing left behind
+        bnn.manual_seed(8)
+        with torch.no_grad(), _mc.McContext(4, 24, 0):                                # no plan: layers draw for themselves
+            y_layer = net._forward(x).view(4, 24, 10)
+        assert torch.equal(y_plan, y_layer)
+        # training through the plan: gradients exist and are finite
+        bnn.manual_seed(8)
+        ys = net.forward_stacked(x, 4)
+        ys.sum().backward()
+        g = net.layers[0].weight.mean.grad
+        assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+    finally:
+        bnn.set_compute("f32")

@@ -228,7 +228,13 @@ def test_kl_large_workgroup_paths(env, total):
     assert abs(out[3] - scalar) <= 1e-5 * (1 + abs(scalar))
 
 
-def test_kl_second_pass_inside_mc_reduction(env):
+@pytest.fixture
+def restore_draw_once(env):
+    yield
+    env["ops"].DRAW_ONCE_BF16 = True
+
+
+def test_kl_second_pass_inside_mc_reduction(env, restore_draw_once):
     """ops.kl_normal_begin + ops.mc_mean(kl=...) (bnn_kl_forward_partial / bnn_mc_sum_kl: KL's second pass as one extra
     workgroup of the MC reduction) == ops.kl_normal + ops.mc_mean, bit for bit; the epoch cell is bumped once."""
     dev = env["dev"]
@@ -251,9 +257,11 @@ def test_kl_second_pass_inside_mc_reduction(env):
     with pytest.raises(Exception):
         ops.mc_mean(y, kl=h)                        # a handle is finished once
     # carry=True: the first pass rides in a narrow layer's launch (bnn_linear_forward_sampled_kl); same bits, and the
-    # layer's own output is unchanged
+    # layer's own output is unchanged.  (The FUSED kernels: in bf16 mode the default is now the draw-once path, whose
+    # draw launch carries the KL instead -- tests/test_dense_path.py::test_draw_multi_many_layers_and_kl_carry.)
     from bayesianneuralnetworks_amd._rng import DrawKey
     from bayesianneuralnetworks_amd import _lib
+    ops.DRAW_ONCE_BF16 = False
     x = torch.randn(8, 512, 1200, device=dev).to(torch.bfloat16)
     mw, rw, mb, rb = mus[4].view(10, 1200), rhos[4].view(10, 1200), mus[5], rhos[5]
     kw, kb = DrawKey(7, 1, 0, 8, 0), DrawKey(7, 2, 0, 8, 0)
@@ -281,6 +289,7 @@ def test_kl_second_pass_inside_mc_reduction(env):
     ops.mc_mean(y, kl=h5)
     assert np.array_equal(N(h5.out), N(ops.kl_normal(mus[3:], rhos[3:], pri[3:], 1.0)))
     assert np.array_equal(N(yf), N(yf_ref))
+    ops.DRAW_ONCE_BF16 = True
     # a large reduction (more MC workgroups than the 2048-block cap) next to a one-tensor KL
     y2 = torch.randn(3, 700001, device=dev)
     h2 = ops.kl_normal_begin(mus[:1], rhos[:1], pri[:1], 1.0)
@@ -334,6 +343,7 @@ def test_large_batch_draws_once(env, mode):
         x = x.bfloat16()
     old = ops.DRAW_ONCE_MIN_ROWS
     try:
+        ops.DRAW_ONCE_BF16 = False                 # (round-1 kernels: fused draw against K1 + the same kernel on explicit weights)
         ops.DRAW_ONCE_MIN_ROWS = 1 << 30
         fused = ops._linear_sampled_raw(x, M * K, M, mu, rho, mb, rb, kw, kb, comp, relu=True, out_dtype=odt)
         ops.DRAW_ONCE_MIN_ROWS = 2048
@@ -342,6 +352,7 @@ def test_large_batch_draws_once(env, mode):
         assert env["lib"].bnn_launch_count() == before + 3           # K1 (weights), K1 (bias), the contraction
     finally:
         ops.DRAW_ONCE_MIN_ROWS = old
+        ops.DRAW_ONCE_BF16 = True
     assert np.array_equal(N(once.float()), N(fused.float()))
     assert float(once.float().min()) == 0.0                            # the fused ReLU ran
 
