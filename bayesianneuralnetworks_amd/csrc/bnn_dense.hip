@@ -304,33 +304,55 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     // two lane-constant bases (h = 0, 1) + compile-time offsets (16-row block, stage)
     const int fbase0 = fi * 128 + (((0 + fq) ^ (fi & 7)) << 4);
     const int fbase1 = fi * 128 + (((4 + fq) ^ (fi & 7)) << 4);
-    auto step = [&](auto stage_c) {
-        constexpr int stage = decltype(stage_c)::value;
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+    // Fragment registers are double-buffered over the two 32-k halves of a step, and barrier t + 1 sits in the MIDDLE of
+    // step t: [reads (t, h1)] [MFMAs (t, h0)] [reads done -> barrier t + 1] [reads (t + 1, h0)] [MFMAs (t, h1)].  Every group
+    // of fragment reads is issued one MFMA group (20 MFMAs, 320 cycles) before its first use, and a wave reaches the
+    // barrier with its reads of stage t complete -- the invariant the loaders refill on.
+    uint4 fa[2][TM], fb[2][TN];
+    auto rd = [&](auto buf_c, auto stage_c, auto h_c) {
+        constexpr int buf = decltype(buf_c)::value, stage = decltype(stage_c)::value, h = decltype(h_c)::value;
         if constexpr (DIAG == 1) return;
-        const char *As = a_ring + stage * A_STAGE;
-        const char *Bs = b_ring + stage * B_STAGE;
+        const char *As = a_ring + stage * A_STAGE + (h ? fbase1 : fbase0);
+        const char *Bs = b_ring + stage * B_STAGE + (h ? fbase1 : fbase0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int fb = h ? fbase1 : fbase0;
-            uint4 af[TM], bfr[TN];
+        for (int b = 0; b < TN; ++b) fb[buf][b] = *reinterpret_cast<const uint4 *>(Bs + b * 2048);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const uint4 *>(Bs + fb + b * 2048);
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const uint4 *>(As + fb + a * 2048);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
-                                                                        __builtin_bit_cast(bf16x8, bfr[b]), acc[a][b], 0, 0, 0);
-        }
+        for (int a = 0; a < TM; ++a) fa[buf][a] = *reinterpret_cast<const uint4 *>(As + a * 2048);
     };
+    auto mm = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        if constexpr (DIAG == 1) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[buf][a]),
+                                                                    __builtin_bit_cast(bf16x8, fb[buf][b]), acc[a][b], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto step = [&](auto stage_c, auto next_c, bool more) {
+        rd(I1{}, stage_c, I1{});                        // (t, h1) -> buffer 1
+        __builtin_amdgcn_sched_barrier(0);
+        mm(I0{});                                       // (t, h0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of stage t have returned
+            __builtin_amdgcn_s_barrier();               // barrier t + 1
+            asm volatile("" ::: "memory");
+            rd(I0{}, next_c, I0{});                     // (t + 1, h0) -> buffer 0
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mm(I1{});                                       // (t, h1)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    __builtin_amdgcn_s_barrier();                       // barrier 0
+    asm volatile("" ::: "memory");
+    rd(I0{}, I0{}, I0{});
     for (int kt = 0; kt < nk; kt += ST) {
-        step(std::integral_constant<int, 0>{});
-        if (kt + 1 < nk) step(std::integral_constant<int, 1>{});
-        if (kt + 2 < nk) step(std::integral_constant<int, 2>{});
+        step(I0{}, I1{}, kt + 1 < nk);
+        if (kt + 1 < nk) step(I1{}, std::integral_constant<int, 2>{}, kt + 2 < nk);
+        if (kt + 2 < nk) step(std::integral_constant<int, 2>{}, I0{}, kt + 3 < nk);
     }
     __builtin_amdgcn_s_setprio(0);
 

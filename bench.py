@@ -399,32 +399,89 @@ def _time_launches(fn, dev, iters, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_roofline(net, x, mode, dev, iters=50):
-    """Dominant kernel = the sampled layer 2 (512 x 1200 x 1200, 8 samples in one layer call).  Average
-    duration from events on the launch stream; algorithmic FLOPs."""
-    from bayesianneuralnetworks_amd import _mc
+def _graph_time(fn, dev, reps=10, iters=20):
+    """us per call of fn(), replayed from a HIP graph of `reps` calls (eager Python launches are host-bound at these sizes)."""
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
+        fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    return _time_launches(g.replay, dev, iters, warm=2) * 1e3 / reps
+
+
+def kernel_roofline(net, x, mode, dev):
+    """Dominant MFMA kernel = the contraction of layer 2 (512 x 1200 x 1200, 8 samples in one launch).  bf16 mode: the
+    dense GEMM on the drawn weights (k_dense_bf16; its weights come from the step's ONE draw launch, priced under
+    `roofline_draw`); fp32 mode: the fused sampled kernel.  Average launch duration from events on the launch stream
+    around graph replays of 10 launches; algorithmic FLOPs."""
+    from bayesianneuralnetworks_amd import _mc, ops
+    from bayesianneuralnetworks_amd._rng import DrawKey
     layer = net.layers[2]
     h = torch.randn(SAMPLES * BATCH, DIMS[1], device=dev).relu_()
-    if mode == "bf16":
-        # the hidden activation the step really feeds this layer: bf16, 128-B aligned rows (what layer 1's epilogue writes)
-        hb = torch.zeros(SAMPLES * BATCH, (DIMS[1] + 63) // 64 * 64, dtype=torch.bfloat16, device=dev)
-        hb[:, :DIMS[1]] = h
-        h = hb[:, :DIMS[1]]
-    layer.compute = mode
-    with torch.no_grad(), _mc.McContext(SAMPLES, BATCH, 0):
-        ms = _time_launches(lambda: layer(h), dev, iters)
-    layer.compute = None
     flops = 2.0 * SAMPLES * BATCH * DIMS[1] * DIMS[2]
-    ach = flops / (ms * 1e-3) / 1e12
-    # parameter bytes the launch must touch at least once: mu, rho of W and b
     pbytes = 8.0 * (DIMS[1] * DIMS[2] + DIMS[2])
     tag = "layer2_" + mode
     traffic, src = pmc_traffic(tag)
-    return {"kernel": "sampled layer 2, 512x1200x1200 x8 samples (%s)" % tag, "bound": "mfma",
-            "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s", "frac": round(ach / PEAK[mode], 4),
-            "traffic": traffic, "traffic_source": src, "avg_launch_us": round(ms * 1e3, 2),
-            "algorithmic_flop_per_launch": flops, "algorithmic_param_bytes_per_launch": pbytes,
-            "algorithmic_bytes_per_launch": pbytes + SAMPLES * BATCH * (DIMS[1] * (2 if mode == "bf16" else 4) + DIMS[2] * 4)}
+    out = {"bound": "mfma", "peak": PEAK[mode], "unit": "TFLOP/s", "traffic": traffic, "traffic_source": src,
+           "algorithmic_flop_per_launch": flops}
+    if mode == "bf16":
+        # the hidden activation the step really feeds this layer: bf16, 128-B aligned rows (what layer 1's epilogue writes)
+        hb = torch.zeros(SAMPLES, BATCH, (DIMS[1] + 63) // 64 * 64, dtype=torch.bfloat16, device=dev)
+        hb[:, :, :DIMS[1]] = h.view(SAMPLES, BATCH, -1)
+        hv = hb[:, :, :DIMS[1]]
+        kw, kb = DrawKey(1, 1, 0, SAMPLES, 0), DrawKey(1, 2, 0, SAMPLES, 0)
+        spec = (layer.weight.mean.detach(), layer.weight.scale.detach(), layer.bias.mean.detach(), layer.bias.scale.detach(), kw, kb)
+        pre = ops.draw_layers([spec], SAMPLES)[0]
+        ld = hb.shape[2]
+        us = _graph_time(lambda: ops._dense_raw(hv, BATCH * ld, BATCH, pre, DIMS[1], True, torch.bfloat16, ldx=ld, pad_rows=True), dev)
+        us_draw = _graph_time(lambda: ops.draw_layers([spec], SAMPLES), dev)
+        ach = flops / us / 1e6
+        out.update({"kernel": "k_dense_bf16<4,5>: layer 2, 512x1200x1200 x8 samples on drawn weights (%s)" % tag,
+                    "achieved": round(ach, 2), "frac": round(ach / PEAK[mode], 4), "avg_launch_us": round(us, 2),
+                    "algorithmic_bytes_per_launch": SAMPLES * (BATCH * DIMS[1] * 2 + DIMS[2] * DIMS[1] * 2 + BATCH * DIMS[2] * 2),
+                    "layer_end_to_end": {"draw_us": round(us_draw, 2), "total_us": round(us + us_draw, 2),
+                                         "tflops": round(flops / (us + us_draw) / 1e6, 1),
+                                         "frac": round(flops / (us + us_draw) / 1e6 / PEAK[mode], 4),
+                                         "note": "layer 2 alone = its own draw launch (8 x 1.44 M weights) + the contraction; in the step the "
+                                                 "draw of all three layers is ONE launch (roofline_draw)"}})
+        return out
+    layer.compute = mode
+    with torch.no_grad(), _mc.McContext(SAMPLES, BATCH, 0):
+        us = _graph_time(lambda: layer(h), dev)
+    layer.compute = None
+    ach = flops / us / 1e6
+    out.update({"kernel": "k_linear_sym<bf16x3>: sampled layer 2, 512x1200x1200 x8 samples, fused draw (%s)" % tag,
+                "achieved": round(ach, 2), "frac": round(ach / PEAK[mode], 4), "avg_launch_us": round(us, 2),
+                "algorithmic_param_bytes_per_launch": pbytes,
+                "algorithmic_bytes_per_launch": pbytes + SAMPLES * BATCH * (DIMS[1] * 4 + DIMS[2] * 4)})
+    return out
+
+
+def draw_roofline(net, dev):
+    """The step's draw launch: every posterior tensor of the MLP x 8 MC samples in ONE k_draw_multi (bf16 mode).
+    Algorithmic bytes: 8 per posterior scalar read (mu, rho) + 2 per drawn weight written.  The kernel is VALU-bound,
+    not HBM-bound: one Philox4x32-10 block + two Box-Muller pairs are ~74 VALU instructions per 4 weights, of which the
+    20 v_mad_u64_u32 and the 8 transcendentals issue at quarter rate: ~21 us of VALU issue on 1024 SIMDs."""
+    from bayesianneuralnetworks_amd import ops
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    specs = []
+    for i, L in enumerate(m for m in net.layers if hasattr(m, "weight")):
+        specs.append((L.weight.mean.detach(), L.weight.scale.detach(), L.bias.mean.detach(), L.bias.scale.detach(),
+                      DrawKey(1, 2 * i + 1, 0, SAMPLES, 0), DrawKey(1, 2 * i + 2, 0, SAMPLES, 0)))
+    us = _graph_time(lambda: ops.draw_layers(specs, SAMPLES), dev)
+    nbytes = 8.0 * P_SCALARS + 2.0 * SAMPLES * P_SCALARS
+    gbs = nbytes / us / 1e3
+    traffic, src = pmc_traffic("draw_multi")
+    return {"kernel": "k_draw_multi: 6 posterior tensors (2.395 M scalars) x 8 MC samples, one launch", "bound": "hbm",
+            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "traffic": traffic, "traffic_source": src, "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": nbytes,
+            "draws_per_launch": SAMPLES * P_SCALARS, "gdraws_per_s": round(SAMPLES * P_SCALARS / us / 1e3, 2)}
 
 
 def conv_roofline(which, mode, dev, iters=20):
@@ -695,6 +752,8 @@ def main(argv=None):
             line["f32"] = {"value": round(results["f32"][0], 1), "ms_per_step": round(results["f32"][1], 4),
                            "note": "same step in the 1e-5 parity mode (fp32 operands; wide layers as bf16x3 splits on the bf16 MFMA)"}
         line["roofline"] = kernel_roofline(net, x, args.dtype, dev)
+        if args.dtype == "bf16":
+            line["roofline_draw"] = draw_roofline(net, dev)
         if world == 1 and not args.no_legs:
             line["roofline_sampler"] = sampler_roofline(dev)
             line["roofline_kl"] = kl_roofline(dev)

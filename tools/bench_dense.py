@@ -54,6 +54,12 @@ def l2_padded():
                                      _lib.ptr(yb), B * 1200, 1200, B, 1200, 1200, S, _lib.FLAG_RELU | _lib.FLAG_Y_BF16, _lib.stream_ptr(dev)), "dense")
 us = t(l2_padded)
 print("dense layer 2, activation rows padded to 1216 (128-B aligned): %.2f us = %.1f TFLOP/s" % (us, 2.0 * S * B * 1200 * 1200 / us / 1e6))
+# fixed cost of a dense launch at the layer-2 grid: ONE 64-k step (prologue + epilogue + launch ramp)
+w1 = torch.zeros(S, 1200, 64, device=dev, dtype=torch.bfloat16)
+p1 = ops.Predrawn(w1, pre[1].b, None, None)
+h64 = hp[:, :, :64]
+us = t(lambda: ops._dense_raw(h64, B * 1216, B, p1, 64, True, torch.bfloat16, ldx=1216, pad_rows=True))
+print("dense layer-2 grid with K = 64 overhead probe (1 step): %.2f us" % us)
 # 4096^3, one sample
 M = N = K = 4096
 a = torch.randn(M, K, device=dev).bfloat16()
