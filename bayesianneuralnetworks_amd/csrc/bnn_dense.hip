@@ -54,6 +54,7 @@ struct DrawTensorDev {
     int64_t out_sample_stride;  // elements
     int32_t rows, cols, ld;     // (rows, cols) posterior, output rows of ld >= cols elements (zeros beyond cols)
     int32_t bf16;               // output dtype
+    int32_t perm_taps;          // > 1: a conv weight (O, C, KH, KW) written tap-major: column c * taps + t -> t * (cols / taps) + c
     int32_t first_item;         // first work item (8-column group) of this tensor within the launch
     RngDev rng;
 };
@@ -76,7 +77,7 @@ template <int U>
 __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
 {
     if ((int)blockIdx.x >= L.draw_blocks) {
-        kl_piggy_block(L.kl, (int)blockIdx.x - L.draw_blocks);
+        if (blockIdx.y == 0) kl_piggy_block(L.kl, (int)blockIdx.x - L.draw_blocks);
         return;
     }
     const int item0 = (int)blockIdx.x * 256;
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     const int64_t t_stride = L.t[ti].out_sample_stride;
     const int t_rows = L.t[ti].rows, t_cols = L.t[ti].cols, t_ld = L.t[ti].ld;
     const bool t_bf16 = L.t[ti].bf16 != 0;
+    const int t_taps = L.t[ti].perm_taps;
     const RngDev rng = L.t[ti].rng;
     const int S = L.nsamples;
     const int local = item0 + (int)threadIdx.x - L.t[ti].first_item;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     if (c0 >= t_cols) {
         // padding columns: zeros (the dense kernel's K tail multiplies them with clamped, finite activations)
         for (int s = 0; s < S; ++s) {
+            if (s % (int)gridDim.y != (int)blockIdx.y) continue;
             if (t_bf16) *reinterpret_cast<uint4 *>(dst0 + s * sbytes) = make_uint4(0u, 0u, 0u, 0u);
             else
                 for (int j = 0; j < 8; ++j)
@@ -132,9 +135,11 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     const uint32_t edev = rng_epoch_dev(rng);
     const PhiloxKeys keys = philox_keys(rng.key0, rng.key1);
     const uint32_t blk = (uint32_t)(e0 >> 2);
-    const bool vec_store = t_bf16 && nval == 8;
+    const bool vec_store = t_bf16 && nval == 8 && t_taps <= 1;
+    // gridDim.y > 1 (small launches: a conv weight is 18 workgroups): the samples are dealt over blockIdx.y as well -- sigma is
+    // recomputed per slice, but a thread is no longer one long serial chain of S draws on a mostly idle chip
 #pragma unroll U
-    for (int s = 0; s < S; ++s) {
+    for (int s = (int)blockIdx.y; s < S; s += (int)gridDim.y) {
         const uint32_t sample = rng.sample0 + (uint32_t)s;
         const float4 za = eps4(rng, keys, edev, blk, sample);
         const float4 zb = eps4(rng, keys, edev, blk + 1u, sample);
@@ -149,6 +154,15 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
             o.x = pack_bf16x2(w[0], w[1]); o.y = pack_bf16x2(w[2], w[3]);
             o.z = pack_bf16x2(w[4], w[5]); o.w = pack_bf16x2(w[6], w[7]);
             *reinterpret_cast<uint4 *>(dst) = o;
+        } else if (t_taps > 1) {
+            // conv weight: element (o, c, tap) goes to column tap * C + c of row o (the implicit-GEMM kernel walks K
+            // tap by tap, 64 channels at a time); the eps stream is addressed by the ORIGINAL flat index all the same
+            const int Cn = t_cols / t_taps;
+            uint16_t *rowp = reinterpret_cast<uint16_t *>(t_out + ((int64_t)row * t_ld) * 2 + s * sbytes);
+            for (int j = 0; j < nval; ++j) {
+                const int col = c0 + j, c = col / t_taps, tp = col - c * t_taps;
+                rowp[tp * Cn + c] = f2bf(w[j]);
+            }
         } else {
             // a bias, or the ragged end of a row whose padding starts inside this group: values, then zeros
             for (int j = 0; j < 8; ++j) {
@@ -478,6 +492,249 @@ __global__ __launch_bounds__(256) void k_head_bf16(const DenseParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ (4) conv2d, implicit GEMM
+// y[s] = conv2d(x[s], w_s, b_s) on drawn weights, groups = 1: M = (image, output pixel), N = O, K = (tap, channel).
+// No im2col panel anywhere: a workgroup keeps ITS images resident in LDS -- read from memory once (fp32 NCHW, coalesced
+// 16-B loads), rounded to bf16 and laid out [image][pixel][channel], UNPADDED -- and the im2col happens in the ADDRESS
+// of the A-fragment read: output pixel (oh, ow), tap (kh, kw), channels c0 .. c0 + 7 are 16 contiguous bytes of input
+// pixel (oh sh - ph + kh dh, ow sw - pw + kw dw); a tap that falls into the padding reads any valid pixel and the
+// fragment is replaced by zeros (four v_cndmask).  The drawn weights arrive tap-major (bnn_draw_multi, taps = KH KW:
+// column t C + c), so a 64-k step is one tap x 64 channels and the B tile streams through an LDS-DMA ring (loader waves
+// 4-7, one barrier per step; ST stages, ST - 1 in flight: the steps are short -- 16 or 32 MFMAs -- so the ring is deep).
+// 16-B chunk j of a pixel's channel vector sits at position j ^ swz(pixel) (C = 64: (pixel >> 1) & 7, 128-B pixels;
+// C % 128 == 0: pixel & 15).  The static LDS block is sized for TWO workgroups per CU: the phases of a workgroup (image
+// fill: memory-bound; k loop; output copy: memory-bound) do not overlap each other, those of two workgroups do.
+// Output: the tile's (images x O x pixels) block is contiguous in NCHW when the tile spans all O channels (it does:
+// BN = O), so it is staged in LDS and leaves as whole 16-B chunks.
+// Measured on the way (LeNet shape, 8 x 1024 images): padded images + whole-region zero fill, 3-stage ring, one
+// workgroup per CU: 48 us, of which fill 20, k loop 14 (DMA-latency-bound), skeleton 11.
+struct ConvParams {
+    const float *X;
+    int64_t x_sample_stride;    // elements; 0 = input shared by all samples
+    const uint16_t *W;          // S x O x ldw bf16, tap-major, zero-padded rows
+    int64_t w_sample_stride;
+    int64_t ldw;
+    const float *bias;          // S x O fp32 or NULL
+    int64_t bias_sample_stride;
+    float *Y;                   // S x B x O x (OH * OW) fp32
+    int64_t y_sample_stride;
+    int32_t B, C, H, Wd, O, KH, KW, sh, sw, ph, pw, dh, dw, OH, OW;
+    int32_t S, IMG, ntiles;     // images per workgroup, workgroups per sample
+    int32_t img_bytes;          // H * W * C * 2
+    int32_t flags;
+};
+
+constexpr int kConvLds = 78 * 1024;      // two workgroups per CU (O = 64)
+constexpr int kConvLdsBig = 136 * 1024;  // one workgroup per CU with a 6-stage ring (O = 128: 16-KB stages, 32 MFMAs per step)
+
+template <int TN, int ST, int LDSB>
+__global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(const ConvParams p)
+{
+    constexpr int NWV = 4, TM = 2, WM = 32, BN = 16 * TN;
+    constexpr int B_TOTAL = BN / 8, NBP = B_TOTAL / NWV;        // B pieces per loader per stage (TN = 4: 2, TN = 8: 4)
+    constexpr int B_STAGE = BN * 128;
+    static_assert(B_TOTAL % NWV == 0, "B pieces split evenly over the loaders");
+    static_assert(ST >= 2 && ST * B_STAGE < LDSB, "ring");
+    __shared__ __attribute__((aligned(16))) char lds[LDSB];
+    const int P = p.OH * p.OW, HW = p.H * p.Wd;
+    const int img_region = p.IMG * p.img_bytes;
+    char *b_ring = lds + img_region;
+
+    int s, t;
+    {
+        const int L = (int)blockIdx.x;
+        if (p.S % 8 == 0) { const int idx = L >> 3; s = (L & 7) + 8 * (idx / p.ntiles); t = idx % p.ntiles; }
+        else { s = L / p.ntiles; t = L % p.ntiles; }
+    }
+    const int b0 = t * p.IMG;
+    const int imgs = (p.B - b0 < p.IMG) ? p.B - b0 : p.IMG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool swz16 = (p.C >> 3) >= 16;
+    auto swz = [&](int pl) { return swz16 ? (pl & 15) : ((pl >> 1) & 7); };
+    const int nk = p.KH * p.KW * (p.C >> 6);
+
+    // ---- loaders put the first ST - 1 weight stages in flight before anything else
+    const int lw = wave - NWV;
+    uint32_t b_off[NBP];
+    uint32_t b_lds = 0;
+    const char *w_base = reinterpret_cast<const char *>(p.W + (int64_t)s * p.w_sample_stride);
+    auto issue = [&](int kt) {
+        const int stage = kt % ST;
+#pragma unroll
+        for (int j = 0; j < NBP; ++j)
+            dma_piece(w_base, b_off[j] + (uint32_t)(kt * 128), b_lds + (uint32_t)(stage * B_STAGE + (lw + NWV * j) * 1024));
+    };
+    if (wave >= NWV) {
+        b_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(b_ring));
+        const int prow = lane >> 3, schunk = (lane & 7) ^ prow;
+#pragma unroll
+        for (int j = 0; j < NBP; ++j) {
+            int n = (lw + NWV * j) * 8 + prow;
+            n = n < p.O ? n : p.O - 1;
+            b_off[j] = (uint32_t)((int64_t)n * p.ldw * 2) + 16u * (uint32_t)schunk;
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < ST - 1; ++k0)
+            if (k0 < nk) issue(k0);
+    }
+
+    // (p.flags, BNN_CONV_DIAG: timing-only runs with wrong outputs -- 1 skips the image fill, 2 the k loop, 4 the output copy)
+    // ---- phase 0: this tile's images -> LDS (bf16, channel-last, swizzled on the pixel index inside the image).
+    // A thread owns one (channel pair, pixel quad) of the image layout and walks the images: its decomposition -- the only
+    // integer divisions of the phase -- is computed once, every image then costs two 16-B loads and four 4-B LDS writes.
+    {
+        const float *xs = p.X + (int64_t)s * p.x_sample_stride + (int64_t)b0 * p.C * HW;
+        const int Q = (HW + 3) >> 2, CH2 = p.C >> 1;
+        const int per_img = (p.flags & 1) ? 0 : CH2 * Q;
+        const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15u) == 0);
+        const int img_elems = p.C * HW;
+        for (int rem = tid; rem < per_img; rem += 512) {
+            const int cp = rem / Q, q = rem - cp * Q;
+            int dst[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pl = 4 * q + j;                       // pixel index inside the image
+                dst[j] = pl < HW ? pl * (p.C * 2) + (((cp >> 2) ^ swz(pl)) << 4) + (cp & 3) * 4 : -1;
+            }
+            const float *g0 = xs + (int64_t)(2 * cp) * HW + 4 * q;
+            // eight images (16 x 16-B loads) in flight per thread
+            constexpr int UB = 8;
+            for (int il = 0; il < imgs; il += UB) {
+                float va[UB][4], vb[UB][4];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int iu = il + u < imgs ? il + u : imgs - 1;       // past the tile: a duplicate load, not written
+                    const float *g = g0 + (int64_t)iu * img_elems;
+                    if (vec) {
+                        const float4 a = *reinterpret_cast<const float4 *>(g), b = *reinterpret_cast<const float4 *>(g + HW);
+                        va[u][0] = a.x; va[u][1] = a.y; va[u][2] = a.z; va[u][3] = a.w;
+                        vb[u][0] = b.x; vb[u][1] = b.y; vb[u][2] = b.z; vb[u][3] = b.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { va[u][j] = dst[j] >= 0 ? g[j] : 0.f; vb[u][j] = dst[j] >= 0 ? g[HW + j] : 0.f; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (il + u < imgs) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (dst[j] >= 0) *reinterpret_cast<uint32_t *>(lds + (il + u) * p.img_bytes + dst[j]) = pack_bf16x2(va[u][j], vb[u][j]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fi = lane & 15, fq = lane >> 4;
+
+    const int nk_run = (p.flags & 2) ? 0 : nk;
+    if (wave >= NWV) {
+        // =============================== loader ===============================
+        if (nk_run == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int kt = 0; kt < nk_run; ++kt) {
+            // this wave's pieces of step kt have landed: at most min(ST - 2, nk - 1 - kt) younger stages may stay in flight
+            const int younger = nk - 1 - kt < ST - 2 ? nk - 1 - kt : ST - 2;
+            if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NBP) : "memory");
+            else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NBP) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NBP) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NBP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // barrier kt: stage kt complete; stage (kt - 1) % ST is free
+            if (kt + ST - 1 < nk) issue(kt + ST - 1);
+        }
+    } else {
+        // =============================== consumer ===============================
+        // this lane's two A rows (16-row blocks a = 0, 1): output pixel -> input row / column of tap (0, 0)
+        int ih0[TM], iw0[TM], ib[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            int row = wave * WM + a * 16 + fi;
+            row = row < imgs * P ? row : 0;             // slack rows: any valid pixel, results never staged
+            const int il = row / P, pix = row - il * P;
+            const int oh = pix / p.OW, ow = pix - oh * p.OW;
+            ih0[a] = oh * p.sh - p.ph;
+            iw0[a] = ow * p.sw - p.pw;
+            ib[a] = il * p.img_bytes;
+        }
+        const int fb0 = fi * 128 + (((0 + fq) ^ (fi & 7)) << 4), fb1 = fi * 128 + (((4 + fq) ^ (fi & 7)) << 4);
+        const int CB = p.C >> 6;
+        const int pixb = p.C * 2;
+        for (int kt = 0; kt < nk_run; ++kt) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int tap = kt / CB, cb = kt - tap * CB;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const char *Bs = b_ring + (kt % ST) * B_STAGE;
+            int aoff[TM];
+            bool ok[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int ih = ih0[a] + kh * p.dh, iw = iw0[a] + kw * p.dw;
+                ok[a] = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd;
+                const int pl = ok[a] ? ih * p.Wd + iw : 0;
+                aoff[a] = ib[a] + pl * pixb + (((cb * 8 + fq) ^ swz(pl)) << 4);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 af[TM], bfr[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const uint4 *>(Bs + (h ? fb1 : fb0) + b * 2048);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    // chunk (cb 8 + 4 h + fq) ^ swz: h flips bit 2 of the chunk index, i.e. 64 bytes of the address
+                    const uint4 v = *reinterpret_cast<const uint4 *>(lds + (h ? (aoff[a] ^ 64) : aoff[a]));
+                    af[a] = ok[a] ? v : make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
+                                                                            __builtin_bit_cast(bf16x8, bfr[b]), acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: stage the tile as [image][channel][pixel] (its NCHW block is contiguous), then whole 16-B chunks
+    __syncthreads();                                    // every wave is done with the images and the weight ring
+    float *T = reinterpret_cast<float *>(lds);
+    if (wave < NWV) {
+        const float *bias = p.bias ? p.bias + (int64_t)s * p.bias_sample_stride : nullptr;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int o = b * 16 + fi;
+            const float bv = (bias && o < p.O) ? bias[o] : 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row0 = wave * WM + a * 16 + fq * 4;
+                int il = row0 / P, pix = row0 - il * P;         // the lane's 4 rows are 4 consecutive pixels
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (row0 + r < imgs * P && o < p.O) T[(il * p.O + o) * P + pix] = acc[a][b][r] + bv;
+                    if (++pix == P) { pix = 0; ++il; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        float *Yt = p.Y + (int64_t)s * p.y_sample_stride + (int64_t)b0 * p.O * P;
+        const int n = (p.flags & 4) ? 0 : imgs * p.O * P;
+        if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(Yt) & 15u) == 0) {
+            for (int i = tid; i < (n >> 2); i += 512) reinterpret_cast<uint4 *>(Yt)[i] = reinterpret_cast<const uint4 *>(T)[i];
+        } else {
+            for (int i = tid; i < n; i += 512) Yt[i] = T[i];
+        }
+    }
+}
+
 static inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
 }  // namespace bnn
@@ -512,6 +769,8 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         DrawTensorDev &d = L.t[i];
         d.mu = t.mu; d.rho = t.rho; d.out = t.out; d.out_sample_stride = t.out_sample_stride;
         d.rows = (int32_t)t.rows; d.cols = (int32_t)t.cols; d.ld = (int32_t)t.ld; d.bf16 = t.out_dtype == BNN_BF16;
+        d.perm_taps = t.taps > 1 ? t.taps : 1;
+        if (t.taps > 1 && (t.cols % t.taps != 0 || t.out_dtype != BNN_BF16)) { set_error("%s: tensor %d: taps must divide cols (bf16 output)", who, i); return BNN_E_SHAPE; }
         d.first_item = (int32_t)items;
         d.rng = make_rng(&t.rng);
         items += (t.rows * ((t.ld + 7) / 8) + 255) / 256 * 256;     // a workgroup works on one tensor
@@ -527,10 +786,11 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         }
         grid += L.kl.nblocks;
     }
-    static const int variant = [] { const char *e = getenv("BNN_DRAW_UNROLL"); return e ? atoi(e) : 1; }();
-    if (variant == 2) hipLaunchKernelGGL(k_draw_multi<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, L);
-    else if (variant == 4) hipLaunchKernelGGL(k_draw_multi<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, L);
-    else hipLaunchKernelGGL(k_draw_multi<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, L);
+    // fewer than ~4 workgroups per CU: split the samples over gridDim.y too
+    int split = 1;
+    while (split < nsamples && (int64_t)L.draw_blocks * split < 1024) split *= 2;
+    if (split > nsamples) split = nsamples;
+    hipLaunchKernelGGL(k_draw_multi<1>, dim3((unsigned)grid, (unsigned)split), dim3(256), 0, (hipStream_t)stream, L);
     return check_launch(who);
 }
 
@@ -596,6 +856,52 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
         else { if (relu) BNN_DENSE_LAUNCH(8, false, true); else BNN_DENSE_LAUNCH(8, false, false); }
     }
 #undef BNN_DENSE_LAUNCH
+    return check_launch(who);
+}
+
+int bnn_conv2d_dense_forward(const float *x, int64_t x_sample_stride,
+                             const void *w, int64_t w_sample_stride, int64_t ldw,
+                             const float *b, int64_t b_sample_stride,
+                             float *y, int64_t y_sample_stride,
+                             const bnn_conv2d_shape_t *sh, int nsamples, int flags, void *stream)
+{
+    const char *who = "bnn_conv2d_dense_forward";
+    if (!x || !w || !y || !sh) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (sh->B < 1 || sh->C < 1 || sh->H < 1 || sh->W < 1 || sh->O < 1 || sh->KH < 1 || sh->KW < 1 || sh->stride_h < 1 ||
+        sh->stride_w < 1 || sh->pad_h < 0 || sh->pad_w < 0 || sh->dil_h < 1 || sh->dil_w < 1 || nsamples < 1) { set_error("%s: bad shape", who); return BNN_E_SHAPE; }
+    if (flags != 0) { set_error("%s: unknown flags", who); return BNN_E_UNSUPPORTED; }
+    const int OH = (sh->H + 2 * sh->pad_h - sh->dil_h * (sh->KH - 1) - 1) / sh->stride_h + 1;
+    const int OW = (sh->W + 2 * sh->pad_w - sh->dil_w * (sh->KW - 1) - 1) / sh->stride_w + 1;
+    if (OH < 1 || OW < 1) { set_error("%s: kernel larger than the padded input", who); return BNN_E_SHAPE; }
+    // what the kernel is built for (everything else: bnn_conv2d_forward_sampled / bnn_conv2d_forward)
+    const int K = sh->C * sh->KH * sh->KW;
+    const bool ok = sh->groups == 1 && (sh->C == 64 || sh->C % 128 == 0) && (sh->O == 64 || sh->O == 128) &&
+                    ldw >= K && ldw % 8 == 0 && w_sample_stride % 8 == 0 && al16(w) &&
+                    (reinterpret_cast<uintptr_t>(x) & 3u) == 0 && (reinterpret_cast<uintptr_t>(y) & 3u) == 0;
+    if (!ok) { set_error("%s: needs groups = 1, C = 64 or a multiple of 128, O = 64 or 128, tap-major bf16 weights with 16-B aligned rows", who); return BNN_E_UNSUPPORTED; }
+    ConvParams p{};
+    const int64_t img_bytes = (int64_t)sh->H * sh->W * sh->C * 2;
+    const int P = OH * OW;
+    const int st = sh->O == 64 ? 4 : 6;                 // ring stages (8 KB / 16 KB each)
+    const int64_t lds_block = sh->O == 64 ? kConvLds : kConvLdsBig;
+    const int64_t ring = (int64_t)st * sh->O * 128;
+    int img = 128 / P;                                  // rows per workgroup <= 128
+    while (img > 0 && (img * img_bytes + ring > lds_block || (int64_t)img * sh->O * P * 4 > lds_block)) --img;
+    if (img > sh->B) img = sh->B;
+    if (img < 1 || (int64_t)sh->O * ldw * 2 >= ((int64_t)1 << 32)) { set_error("%s: one image (%lld B bf16) + the weight ring do not fit the LDS block, or more than 128 output pixels per image", who, (long long)img_bytes); return BNN_E_UNSUPPORTED; }
+    p.X = x; p.x_sample_stride = x_sample_stride;
+    p.W = reinterpret_cast<const uint16_t *>(w); p.w_sample_stride = w_sample_stride; p.ldw = ldw;
+    p.bias = b; p.bias_sample_stride = b_sample_stride;
+    p.Y = y; p.y_sample_stride = y_sample_stride;
+    p.B = sh->B; p.C = sh->C; p.H = sh->H; p.Wd = sh->W; p.O = sh->O; p.KH = sh->KH; p.KW = sh->KW;
+    p.sh = sh->stride_h; p.sw = sh->stride_w; p.ph = sh->pad_h; p.pw = sh->pad_w; p.dh = sh->dil_h; p.dw = sh->dil_w;
+    static const int cdiag = [] { const char *e = getenv("BNN_CONV_DIAG"); return e ? atoi(e) : 0; }();
+    p.flags = cdiag;
+    p.OH = OH; p.OW = OW; p.S = nsamples; p.IMG = img; p.ntiles = (sh->B + img - 1) / img; p.img_bytes = (int32_t)img_bytes;
+    const int64_t grid = (int64_t)p.ntiles * nsamples;
+    if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
+    if (sh->O == 64) hipLaunchKernelGGL((k_conv_bf16<4, 4, kConvLds>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_conv_bf16<8, 6, kConvLdsBig>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
     return check_launch(who);
 }
 

@@ -66,6 +66,8 @@ __device__ __forceinline__ void store1(void *out, int64_t idx, float v)
 }
 
 // ---------------------------------------------------------------- K1, eps given
+// (eps supplied = the parity mode: sigma to ~1e-6 RELATIVE accuracy, sigma_accurate -- the drawn weight then agrees with the
+// reference's fp32 expression to its last bits; the Philox kernels keep sigma_draw, which every re-created draw shares)
 template <int DT, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_sample_affine_eps(
     const float *__restrict__ mu, const float *__restrict__ rho, const float *__restrict__ eps,
@@ -80,17 +82,17 @@ __global__ __launch_bounds__(kThreads) void k_sample_affine_eps(
             const float4 r = reinterpret_cast<const float4 *>(rho)[v];
             const float4 e = reinterpret_cast<const float4 *>(eps)[v];
             float4 w;
-            w.x = fmaf(sigma_draw(r.x), e.x, m.x);
-            w.y = fmaf(sigma_draw(r.y), e.y, m.y);
-            w.z = fmaf(sigma_draw(r.z), e.z, m.z);
-            w.w = fmaf(sigma_draw(r.w), e.w, m.w);
+            w.x = fmaf(sigma_accurate(r.x), e.x, m.x);
+            w.y = fmaf(sigma_accurate(r.y), e.y, m.y);
+            w.z = fmaf(sigma_accurate(r.z), e.z, m.z);
+            w.w = fmaf(sigma_accurate(r.w), e.w, m.w);
             store4<DT>(out, v, w);
         }
         for (int64_t i = (nvec << 2) + tid; i < n; i += nthreads)
-            store1<DT>(out, i, fmaf(sigma_draw(rho[i]), eps[i], mu[i]));
+            store1<DT>(out, i, fmaf(sigma_accurate(rho[i]), eps[i], mu[i]));
     } else {
         for (int64_t i = tid; i < n; i += nthreads)
-            store1<DT>(out, i, fmaf(sigma_draw(rho[i]), eps[i], mu[i]));
+            store1<DT>(out, i, fmaf(sigma_accurate(rho[i]), eps[i], mu[i]));
     }
 }
 

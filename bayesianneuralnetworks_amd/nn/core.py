@@ -154,3 +154,7 @@ class WeightMultivariateNormal(Module):
     def sample(self):
         noise = torch.rand_like(self.mean).unsqueeze(-1)
         self.sampled = self.mean + torch.matmul(self.stddev, noise).squeeze(-1)
+
+    def sample_with_noise(self, noise):
+        """Parity mode: the reference's expression (core.py:89-92) on caller-supplied noise (its own torch.rand_like draw)."""
+        self.sampled = self.mean + torch.matmul(self.stddev, noise.unsqueeze(-1)).squeeze(-1)

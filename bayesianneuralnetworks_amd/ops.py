@@ -192,7 +192,9 @@ def draw_layers(layers, nsamples, kl=None, stream=None):
         arr = (_lib.DrawTensor * (2 * len(group)))()
         n = 0
         keep = []
-        for mu_w, rho_w, mu_b, rho_b, key_w, key_b in group:
+        for spec in group:
+            mu_w, rho_w, mu_b, rho_b, key_w, key_b = spec[:6]
+            taps = spec[6] if len(spec) > 6 else 0      # KH * KW: a conv weight, written tap-major
             require_cuda_f32(mu_w, "weight.mean")
             require_cuda_f32(rho_w, "weight.scale")
             N, K = mu_w.shape
@@ -201,6 +203,7 @@ def draw_layers(layers, nsamples, kl=None, stream=None):
             t = arr[n]
             t.mu, t.rho, t.rows, t.cols = mu_w.data_ptr(), rho_w.data_ptr(), N, K
             t.out, t.ld, t.out_sample_stride, t.out_dtype = w.data_ptr(), kp, N * kp, _lib.BF16
+            t.taps = taps
             t.rng = _rng_struct(key_w, dev)
             n += 1
             b = None
@@ -211,6 +214,7 @@ def draw_layers(layers, nsamples, kl=None, stream=None):
                 t = arr[n]
                 t.mu, t.rho, t.rows, t.cols = mu_b.data_ptr(), rho_b.data_ptr(), 1, N
                 t.out, t.ld, t.out_sample_stride, t.out_dtype = b.data_ptr(), N, N, _lib.F32
+                t.taps = 0
                 t.rng = _rng_struct(key_b, dev)
                 n += 1
             keep.append((mu_w, rho_w, mu_b, rho_b))
@@ -633,6 +637,21 @@ def _conv_workspace(sh, x_samples, compute, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
+_CONV_LDS = {64: (78 * 1024, 4), 128: (136 * 1024, 6)}       # O -> (LDS block, ring stages) of k_conv_bf16
+
+
+def conv_dense_eligible(sh, OH, OW):
+    """Shapes bnn_conv2d_dense_forward is built for (include/bnn_hip.h): both BASELINE conv layers."""
+    if sh.groups != 1 or not (sh.C == 64 or sh.C % 128 == 0) or sh.O not in (64, 128):
+        return False
+    P = OH * OW
+    if P > 128:
+        return False
+    img_bytes = sh.H * sh.W * sh.C * 2
+    block, st = _CONV_LDS[sh.O]
+    return img_bytes + st * sh.O * 128 <= block and sh.O * P * 4 <= block
+
+
 class _SampledConv2d(torch.autograd.Function):
     """y[s] = conv2d(x[s], w_s, b_s, ...) as an implicit GEMM with in-kernel draws
     (NormalConv2d.forward, conv.py:112-119)."""
@@ -651,18 +670,29 @@ class _SampledConv2d(torch.autograd.Function):
         if OH < 1 or OW < 1:
             raise BnnHipError("conv2d: kernel larger than padded input")
         y = torch.empty((S, sh.B, sh.O, OH, OW), dtype=torch.float32, device=x.device)
-        rw = _rng_struct(key_w, x.device)
-        rb = _rng_struct(key_b, x.device) if mu_b is not None else None
         per = sh.B * sh.C * sh.H * sh.W
         _lib.ensure_workspace(x.device)
+        ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None)
+        ctx.key_w, ctx.key_b, ctx.shared_x, ctx.conv_args, ctx.compute = key_w, key_b, shared_x, conv_args, compute
+        if compute == _lib.COMPUTE_BF16 and DRAW_ONCE_BF16 and conv_dense_eligible(sh, OH, OW) and mu_w.data_ptr() % 16 == 0:
+            # bf16 mode: weights drawn once (tap-major) for the S samples, then the implicit GEMM on them -- images resident
+            # in LDS, im2col in the fragment addresses, no panel (csrc/bnn_dense.hip, k_conv_bf16)
+            K = mu_w[0].numel()
+            pre = draw_layers([(mu_w.reshape(sh.O, K), rho_w.reshape(sh.O, K), mu_b, rho_b, key_w, key_b, sh.KH * sh.KW)], S)[0]
+            kp = pre.w.shape[2]
+            check(_lib.load().bnn_conv2d_dense_forward(ptr(x), 0 if shared_x else per, ptr(pre.w), sh.O * kp, kp,
+                                                        ptr(pre.b), sh.O if pre.b is not None else 0, ptr(y),
+                                                        sh.B * sh.O * OH * OW, ctypes.byref(sh), S, 0, stream_ptr(x.device)),
+                  "bnn_conv2d_dense_forward")
+            return y
+        rw = _rng_struct(key_w, x.device)
+        rb = _rng_struct(key_b, x.device) if mu_b is not None else None
         ws, wsb = _conv_workspace(sh, 1 if shared_x else S, compute, x.device)
         check(_lib.load().bnn_conv2d_forward_sampled(
             ptr(x), 0 if shared_x else per, ptr(mu_w), ptr(rho_w), ptr(mu_b), ptr(rho_b), ptr(y),
             sh.B * sh.O * OH * OW, ctypes.byref(sh), S, ctypes.byref(rw),
             ctypes.byref(rb) if rb is not None else None, compute, 0, ptr(ws), wsb, stream_ptr(x.device)),
             "bnn_conv2d_forward_sampled")
-        ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None)
-        ctx.key_w, ctx.key_b, ctx.shared_x, ctx.conv_args, ctx.compute = key_w, key_b, shared_x, conv_args, compute
         return y
 
     @staticmethod

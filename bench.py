@@ -499,7 +499,7 @@ def conv_roofline(which, mode, dev, iters=20):
     prev = bnn.get_compute()
     bnn.set_compute(mode)
     with torch.no_grad(), _mc.McContext(SAMPLES, B, 0):
-        ms = _time_launches(lambda: layer(x), dev, iters, warm=3)
+        ms = _graph_time(lambda: layer(x), dev) * 1e-3
     bnn.set_compute(prev)
     ach = flops / (ms * 1e-3) / 1e12
     tag = "conv_%s_%s" % (which, mode)

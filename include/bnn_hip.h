@@ -221,6 +221,9 @@ typedef struct bnn_draw_tensor {
     int64_t ld;                 /* >= cols (% 8 == 0 when rows > 1); columns cols .. ld - 1 are written as ZEROS */
     int64_t out_sample_stride;  /* elements */
     int out_dtype;              /* BNN_F32 or BNN_BF16 */
+    int taps;                   /* 0 / 1: rows are written as they are.  KH * KW of a conv weight (O, C, KH, KW) viewed as
+                                 * (O, C * KH * KW): element (o, c, t) is written to column t * C + c (tap-major, what
+                                 * bnn_conv2d_dense_forward reads); the eps stream keeps the original element order */
     bnn_rng_t rng;
 } bnn_draw_tensor_t;
 /* Draws <= 8 tensors x nsamples MC samples in ONE launch.  kl_tensors != NULL: the launch also carries the first
@@ -360,6 +363,20 @@ int bnn_conv2d_forward(const float *x, int64_t x_sample_stride,
                        const bnn_conv2d_shape_t *shape, int nsamples,
                        int compute, int flags,
                        void *workspace, int64_t workspace_bytes, void *stream);
+
+/* The conv on DRAWN weights as a true implicit GEMM (bf16 compute mode; no im2col panel, no workspace): w is what
+ * bnn_draw_multi writes for the (O, C * KH * KW) posterior with taps = KH * KW -- S x O x ldw bf16, tap-major columns
+ * (t * C + c), rows zero-padded to ldw >= roundup(C * KH * KW, 64).  A workgroup keeps its images in LDS (bf16, padded,
+ * channel-last) and gathers the im2col rows in the address of its MFMA fragment reads; the weight tile streams by
+ * LDS-DMA.  x fp32 NCHW (x_sample_stride = 0: shared), b S x O fp32 or NULL, y fp32 NCHW.  Built for groups = 1,
+ * C = 64 or a multiple of 128, O = 64 or 128, <= 128 output pixels per image, one padded image + weight ring within
+ * LDS (both BASELINE conv shapes); BNN_E_UNSUPPORTED otherwise (use bnn_conv2d_forward_sampled).
+ * replaces  F.conv2d(x, *self.sampled, ...)  pytorch_bayesian/nn/conv.py:116-119 */
+int bnn_conv2d_dense_forward(const float *x, int64_t x_sample_stride,
+                             const void *w, int64_t w_sample_stride, int64_t ldw,
+                             const float *b, int64_t b_sample_stride,
+                             float *y, int64_t y_sample_stride,
+                             const bnn_conv2d_shape_t *shape, int nsamples, int flags, void *stream);
 
 /* ---- backward of K2 conv2d through the panel ------------------
  * replaces  autograd through F.conv2d (conv.py:116) for groups == 1, C*KH*KW % 8 == 0.  With

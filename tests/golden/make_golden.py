@@ -301,9 +301,97 @@ def flipout_cases():
         print(name, "y", tuple(y.shape))
 
 
+def mvn_case():
+    """MultivariateNormalLinear(128, 10), the CIFAR10 example's head (examples/CIFAR10/model.py:37):
+    forward with the reference's own noise (torch.rand_like -- UNIFORM, core.py:89-92 -- weight then bias), the
+    multivariate KL through KLDivergence (loss.py:24-28), and autograd gradients of both.  The noise tensors are stored
+    (they are the layer's input as much as x is); the element-wise sqrt of the lower-triangular factor (core.py:69) is
+    part of what the fixture pins."""
+    from pytorch_bayesian.nn import MultivariateNormalLinear
+    torch.manual_seed(41)
+    layer = MultivariateNormalLinear(128, 10)
+    gen = torch.Generator().manual_seed(42)
+    x = torch.randn(16, 128, generator=gen)
+    gy = torch.randn(16, 10, generator=gen)
+    torch.manual_seed(43)
+    uw = torch.rand(10, 128)
+    ub = torch.rand(10)
+    torch.manual_seed(43)
+    xr = x.clone().requires_grad_(True)
+    y = layer(xr)
+    w, b = layer.sampled
+    assert torch.equal(w, layer.weight.mean + torch.matmul(layer.weight.stddev, uw.unsqueeze(-1)).squeeze(-1))
+    assert torch.equal(b, layer.bias.mean + torch.matmul(layer.bias.stddev, ub.unsqueeze(-1)).squeeze(-1))
+    kld = KLDivergence(number_of_batches=5)(Net([layer]))
+    ((y * gy).sum() + kld).backward()
+    np.savez_compressed(os.path.join(OUT, "mvn_linear_128x10.npz"),
+             mu_w=npf(layer.weight.mean), scale_w=npf(layer.weight.scale), mu_b=npf(layer.bias.mean), scale_b=npf(layer.bias.scale),
+             x=npf(x), gy=npf(gy), u_w=npf(uw), u_b=npf(ub), w=npf(w), b=npf(b), y=npf(y),
+             kl=np.float32(kld.item()), n_batches=np.float32(5),
+             g_mu_w=npf(layer.weight.mean.grad), g_scale_w=npf(layer.weight.scale.grad),
+             g_mu_b=npf(layer.bias.mean.grad), g_scale_b=npf(layer.bias.scale.grad), g_x=npf(xr.grad))
+    print("mvn y", tuple(y.shape), "kl", kld.item())
+
+
+def mnist_whole_net():
+    """The shipped example net end to end (examples/MNIST/model.py:20-33: Conv/BatchNorm/ELU prefix, NormalConv2d,
+    NormalLinear, Softmax) with its trained checkpoint, eval mode, 2 MC samples: the state_dict tensors (numbers only,
+    read with weights_only=True), the eps the two forwards consume (torch.manual_seed, randn in the reference's order:
+    per sample, conv weight, conv bias, linear weight, linear bias) and the two softmax outputs + KL."""
+    path = os.path.join(REF, "examples/MNIST/mnist_pretrained.pth")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    sys.path.insert(0, os.path.join(REF, "examples/MNIST"))
+    import model as mnist_model
+    net = mnist_model.BCNN(1, 10, samples=2)
+    net.load_state_dict(sd)
+    net.eval()
+    x = torch.randn(6, 1, 28, 28, generator=torch.Generator().manual_seed(51))
+    torch.manual_seed(52)
+    with torch.no_grad():
+        ys = net(x)
+    kld = KLDivergence()(net)
+    d = {"sd__" + k.replace(".", "__"): v.detach().cpu().numpy() for k, v in sd.items()}
+    d.update(x=npf(x), y0=npf(ys[0]), y1=npf(ys[1]), kl=np.float32(kld.item()), eps_seed=np.int64(52), x_seed=np.int64(51))
+    np.savez_compressed(os.path.join(OUT, "mnist_bcnn_pretrained.npz"), **d)
+    print("mnist whole net", tuple(ys[0].shape), "kl", kld.item())
+
+
+def f64_references():
+    """Tolerance bookkeeping: float64 evaluations of the K >= 784 cases next to the reference's
+    own fp32 outputs, so that the tests can state |HIP - f64| <= |reference - f64| with numbers.  Same seeds as
+    north_star_mlp()."""
+    posts = seeded.mlp_posteriors((784, 1200, 1200, 10), seed=0)
+    x = seeded.mlp_input(512, 784, seed=1)
+    shapes = [(tuple(p[0].shape), tuple(p[2].shape)) for p in posts]
+    eps = seeded.eps_like_reference(2, shapes, samples=2)
+    out = {}
+    for s in range(2):
+        h = x.double()
+        h32 = x
+        for li, (mw, rw, mb, rb) in enumerate(posts):
+            ew, eb = eps[s][li]
+            # the fp32 weights the reference forms (core.py:44-45), then the contraction in float64 / in the reference's fp32
+            w = mw + (1e-10 + torch.nn.functional.softplus(rw)) * ew
+            b = mb + (1e-10 + torch.nn.functional.softplus(rb)) * eb
+            h = torch.nn.functional.linear(h, w.double(), b.double())
+            h32 = torch.nn.functional.linear(h32, w, b)
+            if li < 2:
+                h = torch.relu(h)
+                h32 = torch.relu(h32)
+        out["y%d_f64" % s] = h.numpy()
+        out["y%d_ref_err" % s] = np.float64((h32.double() - h).abs().max().item())
+    np.savez(os.path.join(OUT, "mlp_784_1200_1200_10_f64.npz"), **out)
+    print("f64 refs: reference fp32 max err", out["y0_ref_err"], out["y1_ref_err"])
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "flipout":
         flipout_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        mvn_case()
+        mnist_whole_net()
+        f64_references()
         return
     weightnormal_case()
     linear_case("linear_4x3", 3, 4, True, 11, 5)
@@ -319,6 +407,9 @@ def main():
     pretrained_mnist()
     north_star_mlp()
     flipout_cases()
+    mvn_case()
+    mnist_whole_net()
+    f64_references()
 
 
 if __name__ == "__main__":

@@ -254,3 +254,94 @@ def test_draw_plan_is_consumed_once_and_matches_per_layer_draws(env):
         assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
     finally:
         bnn.set_compute("f32")
+
+
+# ------------------------------------------------------------------ conv2d as implicit GEMM on drawn weights
+CONV_CASES = [  # B, C, O, H, W, k, stride, pad, dil, shared_x
+    (5, 64, 64, 6, 6, 3, 2, 1, 1, False),          # the MNIST / FashionMNIST layer (configs[2] shape), ragged last tile
+    (1024, 64, 64, 6, 6, 3, 2, 1, 1, False),       # configs[2] at full size (checked on a slice)
+    (256, 128, 128, 4, 4, 3, 1, 1, 1, False),      # configs[3]
+    (9, 128, 128, 4, 4, 3, 1, 1, 1, True),         # shared input (deterministic prefix), ragged tile
+    (3, 64, 128, 7, 5, 3, 1, 0, 1, False),         # no padding, non-square, H * W % 4 != 0
+    (4, 128, 64, 6, 6, 2, 2, 1, 2, False),         # dilation, even kernel
+    (2, 256, 64, 3, 3, 1, 1, 0, 1, False),         # 1 x 1 kernel, C = 256
+]
+
+
+@pytest.mark.parametrize("B,C,O,H,W,k,st,pad,dil,shared", CONV_CASES)
+def test_conv_dense_path_vs_oracle(env, B, C, O, H, W, k, st, pad, dil, shared):
+    """NormalConv2d in bf16 mode (draw once, tap-major + k_conv_bf16) against the oracle's F.conv2d on the same Philox
+    draws with bf16-rounded inputs / weights (double accumulate) -- 1e-5 of the output scale; and the launch count: one
+    draw + one contraction, no im2col panel."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalConv2d
+    from bayesianneuralnetworks_amd import _mc
+    orc, dev = env["orc"], env["dev"]
+    S = 8 if B >= 256 else 3
+    torch.manual_seed(B + C + O)
+    layer = NormalConv2d(C, O, k, stride=st, padding=pad, dilation=dil).to(dev)
+    x = torch.randn(B if shared else S * B, C, H, W, generator=torch.Generator().manual_seed(1))
+    xd = x.to(dev)
+    bnn.set_compute("bf16")
+    try:
+        bnn.manual_seed(77)
+        n0 = env["lib"].bnn_launch_count()
+        with torch.no_grad(), _mc.McContext(S, B, 0):
+            y = layer(xd)
+        assert env["lib"].bnn_launch_count() == n0 + 2
+    finally:
+        bnn.set_compute("f32")
+    OH, OW = y.shape[-2:]
+    y = N(y).reshape(S, B, O, OH, OW)
+    kw, kb = layer.weight.draw_key, layer.bias.draw_key
+    # the weights the launch drew (same keys -> same launch), back from tap-major to (O, C, KH, KW): bit-identical to K1 ...
+    K = C * k * k
+    pre = env["ops"].draw_layers([(layer.weight.mean.detach().reshape(O, K), layer.weight.scale.detach().reshape(O, K),
+                                   layer.bias.mean.detach(), layer.bias.scale.detach(), kw, kb, k * k)], S)[0]
+    wt = pre.w[:, :, :K].reshape(S, O, k * k, C).permute(0, 1, 3, 2).reshape(S, O, C, k, k)
+    w1 = env["ops"]._sample_affine_philox_raw(layer.weight.mean.detach(), layer.weight.scale.detach(), kw, out_dtype=torch.bfloat16)
+    assert torch.equal(wt, w1) and (pre.w[:, :, K:] == 0).all()
+    # ... and within one bf16 ulp of the oracle's draw (a weight within the eps twin's 1e-6 of a rounding boundary rounds the
+    # other way on one side, which is why the contraction below is checked on the DEVICE's weights)
+    ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0, kw.epoch_host, 0, tuple(layer.weight.shape))
+    w_or = orc.sample_affine(N(layer.weight.mean), N(layer.weight.scale), ew)
+    assert (np.abs(N(wt[0]) - w_or) <= np.abs(w_or) * 2.0 ** -8 + 1e-6).all()
+    nb = min(B, 6)                                              # images checked per sample (first and last ones)
+    sel = sorted(set(list(range(nb // 2)) + list(range(B - (nb - nb // 2), B))))
+    xr = orc.bf16_round(x.numpy())
+    for s in range(S):
+        xs = xr[sel] if shared else xr[s * B:(s + 1) * B][sel]
+        want = orc.conv2d(xs, N(wt[s]), N(pre.b[s]), stride=(st, st), padding=(pad, pad), dilation=(dil, dil))
+        assert allclose_scaled(y[s][sel], want), np.abs(y[s][sel] - want).max()
+
+
+def test_conv_dense_path_equals_panel_path_and_trains(env):
+    """Same keys: the implicit-GEMM path and the round-1 panel path contract the same bf16 products (fp32 sums in another
+    order); the backward (unchanged: panel kernels, re-created draws) runs behind the new forward."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalConv2d
+    from bayesianneuralnetworks_amd import _mc
+    ops, dev = env["ops"], env["dev"]
+    torch.manual_seed(3)
+    layer = NormalConv2d(64, 64, 3, stride=2, padding=1).to(dev)
+    x = torch.randn(4 * 10, 64, 6, 6, device=dev)
+    bnn.set_compute("bf16")
+    try:
+        bnn.manual_seed(5)
+        with torch.no_grad(), _mc.McContext(4, 10, 0):
+            y_new = layer(x)
+        ops.DRAW_ONCE_BF16 = False
+        bnn.manual_seed(5)
+        with torch.no_grad(), _mc.McContext(4, 10, 0):
+            y_old = layer(x)
+        ops.DRAW_ONCE_BF16 = True
+        assert allclose_scaled(N(y_new), N(y_old))
+        bnn.manual_seed(5)
+        xg = x.clone().requires_grad_(True)
+        with _mc.McContext(4, 10, 0):
+            yg = layer(xg)
+        yg.square().sum().backward()
+        assert torch.isfinite(layer.weight.mean.grad).all() and layer.weight.scale.grad.abs().sum() > 0 and xg.grad is not None
+    finally:
+        ops.DRAW_ONCE_BF16 = True
+        bnn.set_compute("f32")

@@ -216,3 +216,46 @@ def test_oracle_prune_score_is_the_reference_log_prob():
     mu, rho = torch.from_numpy(g["mu_w"]), torch.from_numpy(g["rho_w"])
     want = torch.distributions.Normal(mu, 1e-10 + torch.nn.functional.softplus(rho)).log_prob(torch.zeros(()))
     assert np.allclose(orc.prune_score(g["mu_w"], g["rho_w"]), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- round 2: MVN head, shipped MNIST net (CPU side)
+def _mvn_layer(g):
+    import torch
+    from bayesianneuralnetworks_amd.nn import MultivariateNormalLinear
+    layer = MultivariateNormalLinear(128, 10)
+    with torch.no_grad():
+        layer.weight.mean.copy_(torch.from_numpy(g["mu_w"])); layer.weight.scale.copy_(torch.from_numpy(g["scale_w"]))
+        layer.bias.mean.copy_(torch.from_numpy(g["mu_b"])); layer.bias.scale.copy_(torch.from_numpy(g["scale_b"]))
+    return layer
+
+
+def test_mvn_head_host_path_matches_reference_golden():
+    """MultivariateNormalLinear(128, 10) on the CPU: forward on the reference's own uniform noise, the
+    multivariate KL through KLDivergence and all gradients against the fixture the real reference produced."""
+    import torch
+    from bayesianneuralnetworks_amd.nn import KLDivergence, BayesianNetworkModule
+    g = load_golden("mvn_linear_128x10")
+    layer = _mvn_layer(g)
+    layer.weight.sample_with_noise(torch.from_numpy(g["u_w"]))
+    layer.bias.sample_with_noise(torch.from_numpy(g["u_b"]))
+    layer.sampled = (layer.weight.sampled, layer.bias.sampled)
+    assert allclose(layer.sampled[0].detach().numpy(), g["w"]) and allclose(layer.sampled[1].detach().numpy(), g["b"])
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = layer(x, sample=False)
+    assert allclose(y.detach().numpy(), g["y"])
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(1, 1, 1)
+            self.layers = torch.nn.Sequential(layer)
+
+    kl = KLDivergence(number_of_batches=float(g["n_batches"]))(Net())
+    assert abs(kl.item() - float(g["kl"])) <= 1e-5 * abs(float(g["kl"]))
+    ((y * torch.from_numpy(g["gy"])).sum() + kl).backward()
+    for got, want in ((layer.weight.mean.grad, "g_mu_w"), (layer.weight.scale.grad, "g_scale_w"),
+                      (layer.bias.mean.grad, "g_mu_b"), (layer.bias.scale.grad, "g_scale_b"), (x.grad, "g_x")):
+        assert allclose(got.numpy(), g[want], 2e-5), want
+    # the reference's own sampling order under the global generator: weight noise, then bias noise
+    torch.manual_seed(43)
+    y2 = layer(torch.from_numpy(g["x"]))
+    assert allclose(y2.detach().numpy(), g["y"])

@@ -15,14 +15,7 @@ for name, (B, C, O, HW, k, s, p) in {"configs[2] LeNet conv 64->64 k3 s2 p1 on 6
     flop = 2.0 * S * B * OH * OH * O * C * k * k
     for mode in ("bf16", "f32"):
         bnn.set_compute(mode)
+        import bench
         with torch.no_grad(), _mc.McContext(S, B, 0):
-            for _ in range(3):
-                layer(x)
-            torch.cuda.synchronize()
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                layer(x)
-            e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
+            us = bench._graph_time(lambda: layer(x), dev)      # replayed from a HIP graph: eager calls are host-bound here
         print("%s %s: %.1f us per 8-sample launch, %.1f TFLOP/s, %.0f MC-samples/s" % (name, mode, us, flop / us / 1e6, S / us * 1e6))
