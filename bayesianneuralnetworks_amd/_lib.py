@@ -60,7 +60,7 @@ class DrawTensor(ctypes.Structure):
     """bnn_draw_tensor_t"""
     _fields_ = [("mu", ctypes.c_void_p), ("rho", ctypes.c_void_p), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64),
                 ("out", ctypes.c_void_p), ("ld", ctypes.c_int64), ("out_sample_stride", ctypes.c_int64),
-                ("out_dtype", ctypes.c_int), ("taps", ctypes.c_int), ("rng", Rng)]
+                ("out_dtype", ctypes.c_int), ("kind", ctypes.c_int), ("taps", ctypes.c_int), ("rng", Rng)]
 
 
 class Conv2dShape(ctypes.Structure):
@@ -103,6 +103,7 @@ SIGNATURES = {
     "bnn_draw_multi": (_int, [ctypes.POINTER(DrawTensor), _int, _int, ctypes.POINTER(KlTensor), _int, _p, _p]),
     "bnn_dense_forward": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p]),
     "bnn_conv2d_dense_forward": (_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape), _int, _int, _p]),
+    "bnn_conv2d_flipout_forward": (_int, [_p, _p, _i64, _p, _p, _p, ctypes.POINTER(Conv2dShape), _int, _p]),
     "bnn_linear_forward": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,
                                   _int, _int, _int, _p]),
     "bnn_linear_backward_input_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int,

@@ -54,6 +54,7 @@ struct DrawTensorDev {
     int64_t out_sample_stride;  // elements
     int32_t rows, cols, ld;     // (rows, cols) posterior, output rows of ld >= cols elements (zeros beyond cols)
     int32_t bf16;               // output dtype
+    int32_t kind;               // 0: draw mu + sigma eps; 1: mu as it is; 2: sigma = 1e-10 + softplus(rho) (Flipout's two operands)
     int32_t perm_taps;          // > 1: a conv weight (O, C, KH, KW) written tap-major: column c * taps + t -> t * (cols / taps) + c
     int32_t first_item;         // first work item (8-column group) of this tensor within the launch
     RngDev rng;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     const int t_rows = L.t[ti].rows, t_cols = L.t[ti].cols, t_ld = L.t[ti].ld;
     const bool t_bf16 = L.t[ti].bf16 != 0;
     const int t_taps = L.t[ti].perm_taps;
+    const int t_kind = L.t[ti].kind;
     const RngDev rng = L.t[ti].rng;
     const int S = L.nsamples;
     const int local = item0 + (int)threadIdx.x - L.t[ti].first_item;
@@ -119,7 +121,14 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     const int nval = t_cols - c0 < 8 ? t_cols - c0 : 8;
     const bool full = nval == 8 && (((reinterpret_cast<uintptr_t>(t_mu) | reinterpret_cast<uintptr_t>(t_rho)) & 15u) == 0) && (e0 & 3) == 0;
     float m[8], sg[8];
-    if (full) {
+    if (t_kind != 0) {
+        // no draw: the posterior's mean or its stddev themselves (Flipout contracts on both, dense.py:70-83 / conv.py:207-221)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m[j] = j < nval ? (t_kind == 1 ? t_mu[e0 + j] : sigma_accurate(t_rho[e0 + j])) : 0.f;
+            sg[j] = 0.f;
+        }
+    } else if (full) {
         const float4 m0 = *reinterpret_cast<const float4 *>(t_mu + e0), m1 = *reinterpret_cast<const float4 *>(t_mu + e0 + 4);
         const float4 r0 = *reinterpret_cast<const float4 *>(t_rho + e0), r1 = *reinterpret_cast<const float4 *>(t_rho + e0 + 4);
         m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
@@ -141,8 +150,11 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
 #pragma unroll U
     for (int s = (int)blockIdx.y; s < S; s += (int)gridDim.y) {
         const uint32_t sample = rng.sample0 + (uint32_t)s;
-        const float4 za = eps4(rng, keys, edev, blk, sample);
-        const float4 zb = eps4(rng, keys, edev, blk + 1u, sample);
+        float4 za = make_float4(0.f, 0.f, 0.f, 0.f), zb = za;
+        if (t_kind == 0) {
+            za = eps4(rng, keys, edev, blk, sample);
+            zb = eps4(rng, keys, edev, blk + 1u, sample);
+        }
         float w[8];
         w[0] = fmaf(sg[0], za.x, m[0]); w[1] = fmaf(sg[1], za.y, m[1]);
         w[2] = fmaf(sg[2], za.z, m[2]); w[3] = fmaf(sg[3], za.w, m[3]);
@@ -522,12 +534,19 @@ struct ConvParams {
     int32_t S, IMG, ntiles;     // images per workgroup, workgroups per sample
     int32_t img_bytes;          // H * W * C * 2
     int32_t flags;
+    // Flipout (FLIP instantiation): W holds 2 O rows -- the means, then the stddevs -- and
+    //   y[b][o] = conv(x[b], mean)[o] + R[b][o] * conv(x[b] * S[b], stddev)[o]           (conv.py:207-221)
+    const float *sgn_in;        // S: B x C of +-1
+    const float *sgn_out;       // R: B x O of +-1
 };
 
 constexpr int kConvLds = 78 * 1024;      // two workgroups per CU (O = 64)
 constexpr int kConvLdsBig = 136 * 1024;  // one workgroup per CU with a 6-stage ring (O = 128: 16-KB stages, 32 MFMAs per step)
 
-template <int TN, int ST, int LDSB>
+// FLIP: the Flipout estimator in ONE launch -- the tile's columns are [O means | O stddevs] (TN = 2 O / 16), both
+// contractions share the A fragment: the second one takes it with the sign bits of S flipped in (a 16-B mask per
+// (image, 8-channel chunk), built in LDS next to the images), and R multiplies its accumulator in the epilogue.
+template <int TN, int ST, int LDSB, bool FLIP = false>
 __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(const ConvParams p)
 {
     constexpr int NWV = 4, TM = 2, WM = 32, BN = 16 * TN;
@@ -537,8 +556,12 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
     static_assert(ST >= 2 && ST * B_STAGE < LDSB, "ring");
     __shared__ __attribute__((aligned(16))) char lds[LDSB];
     const int P = p.OH * p.OW, HW = p.H * p.Wd;
+    const int CPX = p.C >> 3;                                   // 16-B chunks per pixel
+    const int mask_region = FLIP ? p.IMG * CPX * 16 : 0;        // sign masks [image][chunk]
     const int img_region = p.IMG * p.img_bytes;
-    char *b_ring = lds + img_region;
+    char *masks = lds + img_region;
+    char *b_ring = lds + img_region + mask_region;
+    constexpr int NOUT = FLIP ? BN / 2 : BN;                    // output channels of the tile
 
     int s, t;
     {
@@ -571,7 +594,8 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
 #pragma unroll
         for (int j = 0; j < NBP; ++j) {
             int n = (lw + NWV * j) * 8 + prow;
-            n = n < p.O ? n : p.O - 1;
+            const int nrows = FLIP ? 2 * p.O : p.O;
+            n = n < nrows ? n : nrows - 1;
             b_off[j] = (uint32_t)((int64_t)n * p.ldw * 2) + 16u * (uint32_t)schunk;
         }
 #pragma unroll
@@ -587,6 +611,18 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
         const float *xs = p.X + (int64_t)s * p.x_sample_stride + (int64_t)b0 * p.C * HW;
         const int Q = (HW + 3) >> 2, CH2 = p.C >> 1;
         const int per_img = (p.flags & 1) ? 0 : CH2 * Q;
+        if constexpr (FLIP) {
+            // sign masks: bit 15 of element j set where S[b][8 chunk + j] < 0
+            for (int i = tid; i < imgs * CPX; i += 512) {
+                const int il = i / CPX, ch = i - il * CPX;
+                const float *sp = p.sgn_in + (int64_t)(b0 + il) * p.C + ch * 8;
+                uint32_t w4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w4[j] = (sp[2 * j] < 0.f ? 0x8000u : 0u) | (sp[2 * j + 1] < 0.f ? 0x80000000u : 0u);
+                *reinterpret_cast<uint4 *>(masks + i * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+        }
         const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(xs) & 15u) == 0);
         const int img_elems = p.C * HW;
         for (int rem = tid; rem < per_img; rem += 512) {
@@ -652,7 +688,7 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
     } else {
         // =============================== consumer ===============================
         // this lane's two A rows (16-row blocks a = 0, 1): output pixel -> input row / column of tap (0, 0)
-        int ih0[TM], iw0[TM], ib[TM];
+        int ih0[TM], iw0[TM], ib[TM], mb[TM];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             int row = wave * WM + a * 16 + fi;
@@ -662,6 +698,7 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
             ih0[a] = oh * p.sh - p.ph;
             iw0[a] = ow * p.sw - p.pw;
             ib[a] = il * p.img_bytes;
+            mb[a] = il * CPX * 16;
         }
         const int fb0 = fi * 128 + (((0 + fq) ^ (fi & 7)) << 4), fb1 = fi * 128 + (((4 + fq) ^ (fi & 7)) << 4);
         const int CB = p.C >> 6;
@@ -692,12 +729,22 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
                     const uint4 v = *reinterpret_cast<const uint4 *>(lds + (h ? (aoff[a] ^ 64) : aoff[a]));
                     af[a] = ok[a] ? v : make_uint4(0u, 0u, 0u, 0u);
                 }
+                uint4 afs[TM];
+                if constexpr (FLIP) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const uint4 m = *reinterpret_cast<const uint4 *>(masks + mb[a] + (cb * 8 + 4 * h + fq) * 16);
+                        afs[a] = make_uint4(af[a].x ^ m.x, af[a].y ^ m.y, af[a].z ^ m.z, af[a].w ^ m.w);
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]),
+                    for (int b = 0; b < TN; ++b) {
+                        const uint4 av = (FLIP && b >= TN / 2) ? afs[a] : af[a];
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
                                                                             __builtin_bit_cast(bf16x8, bfr[b]), acc[a][b], 0, 0, 0);
+                    }
             }
         }
     }
@@ -708,7 +755,7 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
     if (wave < NWV) {
         const float *bias = p.bias ? p.bias + (int64_t)s * p.bias_sample_stride : nullptr;
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
+        for (int b = 0; b < NOUT / 16; ++b) {
             const int o = b * 16 + fi;
             const float bv = (bias && o < p.O) ? bias[o] : 0.f;
 #pragma unroll
@@ -717,7 +764,11 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
                 int il = row0 / P, pix = row0 - il * P;         // the lane's 4 rows are 4 consecutive pixels
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (row0 + r < imgs * P && o < p.O) T[(il * p.O + o) * P + pix] = acc[a][b][r] + bv;
+                    if (row0 + r < imgs * P && o < p.O) {
+                        float v = acc[a][b][r] + bv;
+                        if constexpr (FLIP) v = fmaf(p.sgn_out[(int64_t)(b0 + il) * p.O + o], acc[a][b + TN / 2][r], v);
+                        T[(il * p.O + o) * P + pix] = v;
+                    }
                     if (++pix == P) { pix = 0; ++il; }
                 }
             }
@@ -764,12 +815,14 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         if (t.ld % 8 != 0 && t.rows > 1) { set_error("%s: tensor %d: ld %% 8 != 0", who, i); return BNN_E_UNSUPPORTED; }
         if (t.out_dtype == BNN_BF16 && (!al16(t.out) || t.out_sample_stride % 8 != 0 || t.ld % 8 != 0)) { set_error("%s: tensor %d: bf16 output needs 16-B aligned rows", who, i); return BNN_E_ALIGN; }
         if ((reinterpret_cast<uintptr_t>(t.mu) | reinterpret_cast<uintptr_t>(t.rho) | reinterpret_cast<uintptr_t>(t.out)) & 3u) { set_error("%s: tensor %d: misaligned pointer", who, i); return BNN_E_ALIGN; }
-        const int rc = check_rng(&t.rng, nsamples);
+        const int rc = t.kind == 0 ? check_rng(&t.rng, nsamples) : BNN_OK;
         if (rc) { set_error("%s: tensor %d: bad rng", who, i); return rc; }
         DrawTensorDev &d = L.t[i];
         d.mu = t.mu; d.rho = t.rho; d.out = t.out; d.out_sample_stride = t.out_sample_stride;
         d.rows = (int32_t)t.rows; d.cols = (int32_t)t.cols; d.ld = (int32_t)t.ld; d.bf16 = t.out_dtype == BNN_BF16;
         d.perm_taps = t.taps > 1 ? t.taps : 1;
+        d.kind = t.kind;
+        if (t.kind < 0 || t.kind > 2) { set_error("%s: tensor %d: kind must be 0 (draw), 1 (mean) or 2 (stddev)", who, i); return BNN_E_RANGE; }
         if (t.taps > 1 && (t.cols % t.taps != 0 || t.out_dtype != BNN_BF16)) { set_error("%s: tensor %d: taps must divide cols (bf16 output)", who, i); return BNN_E_SHAPE; }
         d.first_item = (int32_t)items;
         d.rng = make_rng(&t.rng);
@@ -859,14 +912,15 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
     return check_launch(who);
 }
 
-int bnn_conv2d_dense_forward(const float *x, int64_t x_sample_stride,
-                             const void *w, int64_t w_sample_stride, int64_t ldw,
-                             const float *b, int64_t b_sample_stride,
-                             float *y, int64_t y_sample_stride,
-                             const bnn_conv2d_shape_t *sh, int nsamples, int flags, void *stream)
+}  // extern "C"
+
+static int conv_dense_launch(const float *x, int64_t x_sample_stride, const void *w, int64_t w_sample_stride, int64_t ldw,
+                             const float *b, int64_t b_sample_stride, const float *sgn_in, const float *sgn_out,
+                             float *y, int64_t y_sample_stride, const bnn_conv2d_shape_t *sh, int nsamples, int flags,
+                             void *stream, const char *who)
 {
-    const char *who = "bnn_conv2d_dense_forward";
-    if (!x || !w || !y || !sh) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    const bool flip = sgn_in != nullptr;
+    if (!x || !w || !y || !sh || (flip && !sgn_out)) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (sh->B < 1 || sh->C < 1 || sh->H < 1 || sh->W < 1 || sh->O < 1 || sh->KH < 1 || sh->KW < 1 || sh->stride_h < 1 ||
         sh->stride_w < 1 || sh->pad_h < 0 || sh->pad_w < 0 || sh->dil_h < 1 || sh->dil_w < 1 || nsamples < 1) { set_error("%s: bad shape", who); return BNN_E_SHAPE; }
     if (flags != 0) { set_error("%s: unknown flags", who); return BNN_E_UNSUPPORTED; }
@@ -875,34 +929,63 @@ int bnn_conv2d_dense_forward(const float *x, int64_t x_sample_stride,
     if (OH < 1 || OW < 1) { set_error("%s: kernel larger than the padded input", who); return BNN_E_SHAPE; }
     // what the kernel is built for (everything else: bnn_conv2d_forward_sampled / bnn_conv2d_forward)
     const int K = sh->C * sh->KH * sh->KW;
-    const bool ok = sh->groups == 1 && (sh->C == 64 || sh->C % 128 == 0) && (sh->O == 64 || sh->O == 128) &&
+    const int bn = flip ? 2 * sh->O : sh->O;            // weight rows of the tile
+    const bool ok = sh->groups == 1 && (sh->C == 64 || sh->C % 128 == 0) && (bn == 64 || bn == 128) &&
                     ldw >= K && ldw % 8 == 0 && w_sample_stride % 8 == 0 && al16(w) &&
                     (reinterpret_cast<uintptr_t>(x) & 3u) == 0 && (reinterpret_cast<uintptr_t>(y) & 3u) == 0;
-    if (!ok) { set_error("%s: needs groups = 1, C = 64 or a multiple of 128, O = 64 or 128, tap-major bf16 weights with 16-B aligned rows", who); return BNN_E_UNSUPPORTED; }
+    if (!ok) { set_error("%s: needs groups = 1, C = 64 or a multiple of 128, O = 64 or 128 (Flipout: 32 or 64), tap-major bf16 weights with 16-B aligned rows", who); return BNN_E_UNSUPPORTED; }
     ConvParams p{};
-    const int64_t img_bytes = (int64_t)sh->H * sh->W * sh->C * 2;
+    const int64_t img_bytes = (int64_t)sh->H * sh->W * sh->C * 2 + (flip ? (sh->C / 8) * 16 : 0);   // + the image's sign masks
     const int P = OH * OW;
-    const int st = sh->O == 64 ? 4 : 6;                 // ring stages (8 KB / 16 KB each)
-    const int64_t lds_block = sh->O == 64 ? kConvLds : kConvLdsBig;
-    const int64_t ring = (int64_t)st * sh->O * 128;
+    const int st = bn == 64 ? 4 : (flip ? 4 : 6);       // ring stages (8 KB / 16 KB each)
+    const int64_t lds_block = bn == 64 ? kConvLds : kConvLdsBig;
+    const int64_t ring = (int64_t)st * bn * 128;
     int img = 128 / P;                                  // rows per workgroup <= 128
     while (img > 0 && (img * img_bytes + ring > lds_block || (int64_t)img * sh->O * P * 4 > lds_block)) --img;
     if (img > sh->B) img = sh->B;
-    if (img < 1 || (int64_t)sh->O * ldw * 2 >= ((int64_t)1 << 32)) { set_error("%s: one image (%lld B bf16) + the weight ring do not fit the LDS block, or more than 128 output pixels per image", who, (long long)img_bytes); return BNN_E_UNSUPPORTED; }
+    if (img < 1 || (int64_t)bn * ldw * 2 >= ((int64_t)1 << 32)) { set_error("%s: one image (%lld B bf16) + the weight ring do not fit the LDS block, or more than 128 output pixels per image", who, (long long)img_bytes); return BNN_E_UNSUPPORTED; }
     p.X = x; p.x_sample_stride = x_sample_stride;
     p.W = reinterpret_cast<const uint16_t *>(w); p.w_sample_stride = w_sample_stride; p.ldw = ldw;
     p.bias = b; p.bias_sample_stride = b_sample_stride;
     p.Y = y; p.y_sample_stride = y_sample_stride;
+    p.sgn_in = sgn_in; p.sgn_out = sgn_out;
     p.B = sh->B; p.C = sh->C; p.H = sh->H; p.Wd = sh->W; p.O = sh->O; p.KH = sh->KH; p.KW = sh->KW;
     p.sh = sh->stride_h; p.sw = sh->stride_w; p.ph = sh->pad_h; p.pw = sh->pad_w; p.dh = sh->dil_h; p.dw = sh->dil_w;
     static const int cdiag = [] { const char *e = getenv("BNN_CONV_DIAG"); return e ? atoi(e) : 0; }();
     p.flags = cdiag;
-    p.OH = OH; p.OW = OW; p.S = nsamples; p.IMG = img; p.ntiles = (sh->B + img - 1) / img; p.img_bytes = (int32_t)img_bytes;
+    p.OH = OH; p.OW = OW; p.S = nsamples; p.IMG = img; p.ntiles = (sh->B + img - 1) / img;
+    p.img_bytes = (int32_t)((int64_t)sh->H * sh->W * sh->C * 2);
     const int64_t grid = (int64_t)p.ntiles * nsamples;
     if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
-    if (sh->O == 64) hipLaunchKernelGGL((k_conv_bf16<4, 4, kConvLds>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((k_conv_bf16<8, 6, kConvLdsBig>), dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
+    const dim3 g((unsigned)grid), blk(512);
+    hipStream_t stq = (hipStream_t)stream;
+    if (flip) {
+        if (bn == 64) hipLaunchKernelGGL((k_conv_bf16<4, 4, kConvLds, true>), g, blk, 0, stq, p);
+        else hipLaunchKernelGGL((k_conv_bf16<8, 4, kConvLdsBig, true>), g, blk, 0, stq, p);
+    } else {
+        if (bn == 64) hipLaunchKernelGGL((k_conv_bf16<4, 4, kConvLds>), g, blk, 0, stq, p);
+        else hipLaunchKernelGGL((k_conv_bf16<8, 6, kConvLdsBig>), g, blk, 0, stq, p);
+    }
     return check_launch(who);
+}
+
+extern "C" {
+
+int bnn_conv2d_dense_forward(const float *x, int64_t x_sample_stride,
+                             const void *w, int64_t w_sample_stride, int64_t ldw,
+                             const float *b, int64_t b_sample_stride,
+                             float *y, int64_t y_sample_stride,
+                             const bnn_conv2d_shape_t *sh, int nsamples, int flags, void *stream)
+{
+    return conv_dense_launch(x, x_sample_stride, w, w_sample_stride, ldw, b, b_sample_stride, nullptr, nullptr, y, y_sample_stride,
+                             sh, nsamples, flags, stream, "bnn_conv2d_dense_forward");
+}
+
+int bnn_conv2d_flipout_forward(const float *x, const void *w, int64_t ldw, const float *sign_in, const float *sign_out,
+                               float *y, const bnn_conv2d_shape_t *sh, int flags, void *stream)
+{
+    if (!sign_in || !sign_out) { set_error("bnn_conv2d_flipout_forward: NULL sign tensor"); return BNN_E_NULL; }
+    return conv_dense_launch(x, 0, w, 0, ldw, nullptr, 0, sign_in, sign_out, y, 0, sh, 1, flags, stream, "bnn_conv2d_flipout_forward");
 }
 
 }  // extern "C"

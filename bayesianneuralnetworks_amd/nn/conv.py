@@ -150,6 +150,10 @@ class FlipOutNormalConvNd(NormalConvNd):
             # conv.py:154-161, so they cannot be folded into the weight)
             comp = _settings.get_compute()
             geo = (self.stride, self.padding, self.dilation, self.groups)
+            needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.mean.requires_grad)
+            if comp == "bf16" and not needs_grad and ops.conv2d_flipout_eligible(x, self.weight.mean, *geo):
+                # one launch for both contractions: shared A tile, S in the fragment's sign bits, R in the epilogue
+                return ops.conv2d_flipout(x, self.weight.mean, self.weight.scale, self.R, self.S, *geo[:3])
             out = ops.conv2d_plain(x, self.weight.mean.unsqueeze(0), None, True, *geo, comp)[0]
             noise = ops.conv2d_plain(x * self.S.expand_as(x), self.weight.stddev.unsqueeze(0), None, True, *geo, comp)[0]
             return out + noise * self.R.expand_as(out)

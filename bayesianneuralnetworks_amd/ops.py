@@ -785,6 +785,62 @@ class _SampledConv2d(torch.autograd.Function):
         return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None
 
 
+def conv2d_flipout_eligible(x, mean, stride, padding, dilation, groups):
+    """bf16 compute, inference: the one-launch Flipout conv (bnn_conv2d_flipout_forward) takes this layer."""
+    if not (DRAW_ONCE_BF16 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and groups == 1):
+        return False
+    O, C, KH, KW = mean.shape
+    if not ((C == 64 or C % 128 == 0) and O in (32, 64) and mean.data_ptr() % 16 == 0):
+        return False
+    sh, OH, OW = _conv_shape(x.shape, mean.shape, stride, padding, dilation, groups)
+    if OH < 1 or OW < 1 or OH * OW > 128:
+        return False
+    block = _CONV_LDS[2 * O][0]
+    return sh.H * sh.W * C * 2 + (C // 8) * 16 + 4 * 2 * O * 128 <= block and O * OH * OW * 4 <= block
+
+
+def conv2d_flipout(x, mean, scale, R, S, stride, padding, dilation):
+    """FlipOutNormalConv2d.forward (conv.py:207-221) in two launches: the mean and the stddev written tap-major as bf16
+    (bnn_draw_multi, kinds 1 / 2 -- no eps), then ONE implicit GEMM that shares the A fragment between the two
+    contractions, with S flipped into its sign bits and R applied in the epilogue (no autograd: inference path)."""
+    x = x.contiguous()
+    require_cuda_f32(x, "x")
+    O, C, KH, KW = mean.shape
+    dev = x.device
+    lib = _lib.load()
+    w2 = flipout_conv_weights(mean, scale)
+    kp = w2.shape[1]
+    sh, OH, OW = _conv_shape(x.shape, mean.shape, stride, padding, dilation, 1)
+    y = torch.empty((sh.B, O, OH, OW), dtype=torch.float32, device=dev)
+    Sf = S.reshape(sh.B, C).to(torch.float32).contiguous()
+    Rf = R.reshape(sh.B, O).to(torch.float32).contiguous()
+    check(lib.bnn_conv2d_flipout_forward(ptr(x), ptr(w2), kp, ptr(Sf), ptr(Rf), ptr(y), ctypes.byref(sh), 0, stream_ptr(dev)),
+          "bnn_conv2d_flipout_forward")
+    return y
+
+
+def flipout_conv_weights(mean, scale):
+    """[O rows of the mean | O rows of the stddev] as bf16, tap-major, rows zero-padded to a multiple of 64 columns: the
+    weight operand of bnn_conv2d_flipout_forward (one bnn_draw_multi launch with kinds 1 / 2 -- no eps)."""
+    mean, scale = mean.detach().contiguous(), scale.detach().contiguous()
+    require_cuda_f32(mean, "weight.mean")
+    require_cuda_f32(scale, "weight.scale")
+    O, C, KH, KW = mean.shape
+    K = C * KH * KW
+    kp = _pad64(K)
+    dev = mean.device
+    lib = _lib.load()
+    w2 = torch.empty((2 * O, kp), dtype=torch.bfloat16, device=dev)
+    arr = (_lib.DrawTensor * 2)()
+    for i, kind in enumerate((1, 2)):
+        t = arr[i]
+        t.mu, t.rho, t.rows, t.cols = mean.data_ptr(), scale.data_ptr(), O, K
+        t.out, t.ld, t.out_sample_stride, t.out_dtype = w2.data_ptr() + i * O * kp * 2, kp, O * kp, _lib.BF16
+        t.kind, t.taps = kind, KH * KW
+    check(lib.bnn_draw_multi(arr, 2, 1, None, 0, None, stream_ptr(dev)), "bnn_draw_multi")
+    return w2
+
+
 def conv2d_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, stride, padding, dilation, groups,
                    compute="f32"):
     return _SampledConv2d.apply(x.contiguous(), mu_w.contiguous(), rho_w.contiguous(),

@@ -221,6 +221,8 @@ typedef struct bnn_draw_tensor {
     int64_t ld;                 /* >= cols (% 8 == 0 when rows > 1); columns cols .. ld - 1 are written as ZEROS */
     int64_t out_sample_stride;  /* elements */
     int out_dtype;              /* BNN_F32 or BNN_BF16 */
+    int kind;                   /* 0: draw mu + sigma(rho) eps (rng used); 1: mu itself; 2: sigma(rho) itself (no eps: Flipout's
+                                 * two operands, nsamples = 1) */
     int taps;                   /* 0 / 1: rows are written as they are.  KH * KW of a conv weight (O, C, KH, KW) viewed as
                                  * (O, C * KH * KW): element (o, c, t) is written to column t * C + c (tap-major, what
                                  * bnn_conv2d_dense_forward reads); the eps stream keeps the original element order */
@@ -377,6 +379,15 @@ int bnn_conv2d_dense_forward(const float *x, int64_t x_sample_stride,
                              const float *b, int64_t b_sample_stride,
                              float *y, int64_t y_sample_stride,
                              const bnn_conv2d_shape_t *shape, int nsamples, int flags, void *stream);
+
+/* Flipout conv2d in ONE launch: y[b] = conv(x[b], mean) + R[b] * conv(x[b] * S[b], stddev) with per-example
+ * sign tensors S (B x C) and R (B x O) of +-1 (conv.py:154-161).  w = [O rows of the mean | O rows of the stddev], bf16
+ * tap-major (bnn_draw_multi with kind = 1 / 2 and taps = KH * KW), ldw >= roundup(C KH KW, 64).  Both contractions share
+ * the A fragment of the implicit GEMM above: S is XOR-ed into its sign bits for the second one, R scales that
+ * accumulator in the epilogue.  No bias (the reference's Flipout conv has none).  Built for 2 O = 64 or 128.
+ * replaces  FlipOutNormalConv2d.forward  pytorch_bayesian/nn/conv.py:207-221 */
+int bnn_conv2d_flipout_forward(const float *x, const void *w, int64_t ldw, const float *sign_in, const float *sign_out,
+                               float *y, const bnn_conv2d_shape_t *shape, int flags, void *stream);
 
 /* ---- backward of K2 conv2d through the panel ------------------
  * replaces  autograd through F.conv2d (conv.py:116) for groups == 1, C*KH*KW % 8 == 0.  With

@@ -345,3 +345,46 @@ def test_conv_dense_path_equals_panel_path_and_trains(env):
     finally:
         ops.DRAW_ONCE_BF16 = True
         bnn.set_compute("f32")
+
+
+@pytest.mark.parametrize("B,C,O,HW,k,st,pad", [(37, 64, 64, 6, 3, 2, 1), (5, 128, 32, 5, 3, 1, 1), (1024, 64, 64, 6, 3, 2, 1)])
+def test_flipout_conv_fused_kernel_vs_oracle(env, B, C, O, HW, k, st, pad):
+    """FlipOutNormalConv2d in bf16 mode without grad = ONE contraction launch (both operands share the A tile; S in the
+    fragment's sign bits, R in the epilogue) against the reference's expression (conv.py:207-221) evaluated by the oracle
+    on bf16-rounded x / mean / stddev -- and against this package's two-convolution fp32 path on the same signs."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import FlipOutNormalConv2d
+    orc, dev = env["orc"], env["dev"]
+    torch.manual_seed(B + C)
+    layer = FlipOutNormalConv2d(C, O, k, stride=st, padding=pad).to(dev)
+    x = torch.randn(B, C, HW, HW, generator=torch.Generator().manual_seed(2)).to(dev)
+    bnn.set_compute("bf16")
+    try:
+        n0 = env["lib"].bnn_launch_count()
+        with torch.no_grad():
+            y = layer(x)
+        assert env["lib"].bnn_launch_count() == n0 + 2            # weights prep + ONE contraction
+        R, S = layer.sampled
+        bnn.set_compute("f32")
+        with torch.no_grad():
+            y32 = layer(x, sample=False)                            # same signs, fp32 two-convolution path
+    finally:
+        bnn.set_compute("f32")
+    sel = sorted(set([0, 1, B // 2, B - 1]))
+    # the weight operand the launch contracts on: bf16 mean / stddev, tap-major -- within one bf16 ulp of the rounded reference
+    # values (a stddev within ~1e-6 of a rounding boundary rounds the other way), and the contraction is checked on THEM
+    K = C * k * k
+    w2 = env["ops"].flipout_conv_weights(layer.weight.mean, layer.weight.scale)
+    assert (w2[:, K:] == 0).all()
+    w2 = N(w2[:, :K]).reshape(2 * O, k * k, C).transpose(0, 2, 1).reshape(2 * O, C, k, k)
+    mean, std = w2[:O], w2[O:]
+    assert (np.abs(mean - N(layer.weight.mean)) <= np.abs(N(layer.weight.mean)) * 2.0 ** -8 + 1e-30).all()
+    assert (np.abs(std - N(layer.weight.stddev)) <= N(layer.weight.stddev) * 2.0 ** -8).all()
+    xs = orc.bf16_round(N(x)[sel])
+    Sn, Rn = N(S).reshape(B, C, 1, 1)[sel], N(R).reshape(B, O, 1, 1)[sel]
+    want = (orc.conv2d(xs, mean, None, stride=(st, st), padding=(pad, pad)) +
+            orc.conv2d(xs * Sn, std, None, stride=(st, st), padding=(pad, pad)) * Rn)
+    got = N(y)[sel]
+    assert allclose_scaled(got, want), np.abs(got - want).max()
+    rms = float(np.sqrt((N(y32) ** 2).mean()))
+    assert np.abs(N(y) - N(y32)).max() <= 2e-2 * max(1.0, rms)     # bf16 operands against fp32 operands
