@@ -68,6 +68,29 @@ class EpsGenerator:
             self._epoch_dev[key] = t
         return t
 
+    def private_epoch_cell(self, device):
+        """Context manager: launches recorded inside read (and bump) a device epoch word of their own instead of the
+        device-wide one -- for captured graphs that are replayed CONCURRENTLY on different streams (two steps in flight
+        must not read one epoch word that either of them bumps).  Yields the cell (4 x int32, word 0 is the epoch)."""
+        gen = self
+
+        class _Cell:
+            def __enter__(self_):
+                self_.key = (device.type, device.index)
+                self_.prev = gen._epoch_dev.get(self_.key)
+                self_.cell = torch.zeros(4, dtype=torch.int32, device=device)
+                gen._epoch_dev[self_.key] = self_.cell
+                return self_.cell
+
+            def __exit__(self_, *exc):
+                if self_.prev is None:
+                    gen._epoch_dev.pop(self_.key, None)
+                else:
+                    gen._epoch_dev[self_.key] = self_.prev
+                return False
+
+        return _Cell()
+
 
 default_generator = EpsGenerator()
 

@@ -119,10 +119,14 @@ class Step:
     second queue costs more in cross-queue dependency latency than it hides).  KL sums and the sum of
     predictions land directly in the packed buffer that the one collective all-reduces."""
 
-    def __init__(self, net, x, rank, world, use_graph, samples=SAMPLES, sample0=None, total_samples=None):
+    def __init__(self, net, x, rank, world, use_graph, samples=SAMPLES, sample0=None, total_samples=None, private=False):
         from bayesianneuralnetworks_amd import ops, _lib, distributed as bd
         from bayesianneuralnetworks_amd._rng import default_generator
         self.net, self.x, self.rank, self.world = net, x, rank, world
+        # private: this step's launches read and bump an epoch word (and use a KL workspace) of their own, so that it can be
+        # replayed concurrently with another step on another stream (PipelinedSteps)
+        self.private = private
+        self.cell = None
         self.samples = samples
         self.sample0 = rank * samples if sample0 is None else sample0
         self.total = world * samples if total_samples is None else total_samples
@@ -151,7 +155,20 @@ class Step:
         self.kl_pos = torch.tensor(self.kl_idx, device=dev, dtype=torch.long)
         self.comm = torch.zeros_like(self.packed)
         self.pending = None
-        if use_graph:
+        if private:
+            with self.gen.private_epoch_cell(dev) as cell:
+                self.cell = cell
+                saved = ops._kl_ws.pop((dev.type, dev.index), None)        # a KL workspace of its own
+                try:
+                    self._capture() if use_graph else self._body()
+                finally:
+                    self.kl_ws = ops._kl_ws.get((dev.type, dev.index))      # the captured launches hold its address: keep it alive
+                    if saved is not None:
+                        ops._kl_ws[(dev.type, dev.index)] = saved
+                    else:
+                        ops._kl_ws.pop((dev.type, dev.index), None)
+            torch.cuda.synchronize(dev)
+        elif use_graph:
             self._capture()
         else:
             self._body()
@@ -190,7 +207,7 @@ class Step:
             ys = self.net.forward_stacked(self.x, self.samples, sample0=self.sample0)   # (S, B, 10)
             # fresh noise on every replay: the reduction also bumps the device epoch (last kernel of the step)
             self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / self.total,
-                             advance=self.gen.epoch_dev(dev), kl=kl_h)
+                             advance=self.gen.epoch_dev(dev), kl=kl_h)        # (the private cell while one is installed)
             if kl_h is not None and self.world > 1:
                 self._kl_scatter()
         return self.packed
@@ -232,25 +249,62 @@ class Step:
             self.pending = None
 
 
+class PipelinedSteps:
+    """`depth` independent steps in flight, each a captured graph with its own buffers, epoch word and KL workspace, replayed
+    round-robin on `depth` streams: the draw of one step (VALU-bound) runs beside the contractions of another (L2 -> LDS
+    ingest / MFMA-bound).  A serving-style throughput pipeline: every step is still one complete stochastic forward + KL +
+    predictive mean over one batch; its latency is that of the single-stream step (reported next to the throughput)."""
+
+    def __init__(self, net, x, depth):
+        dev = x.device
+        self.dev = dev
+        self.steps = [Step(net, x, 0, 1, True, private=True) for _ in range(depth)]
+        self.streams = [torch.cuda.Stream(dev) for _ in range(depth)]
+        self.i = 0
+        self.world = 1
+        cur = torch.cuda.current_stream(dev)
+        for st in self.streams:
+            st.wait_stream(cur)
+
+    def run(self):
+        k = self.i % len(self.steps)
+        self.i += 1
+        with torch.cuda.stream(self.streams[k]):
+            self.steps[k].graph.replay()
+        return self.steps[k].packed
+
+    def finish(self):
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+
 # ------------------------------------------------------------------------------------------ checker
-def oracle_check(step, post, x_cpu, mode, rows=64, tap=None):
+def oracle_check(step, post, x_cpu, mode, rows=64, tap=None, replay=True):
     """CHECKER -- never timed, never on the product path.  Replays the step ONCE more and compares it with
     the CPU oracle (oracle/bnn_oracle.c; pinned to the reference by tests/test_oracle_golden.py) evaluated
     on the draw keys this replay used: KL scalar, `rows` rows of the predictive mean and (if `tap`, a
     (S, rows, N2) buffer a forward hook on layer 2 fills) of the layer-2 output.  bf16 mode: the oracle is
     fed what the kernels feed the MFMA -- bf16-rounded inputs, drawn weights and hidden activations, fp32 bias.
+    replay=False: nothing is launched -- the result the step's LAST replay left behind is checked (epoch = cell - 1): the way
+    to check a result that was produced while other steps were in flight on other streams (PipelinedSteps).
     Returns a dict of the measured errors and the tolerances they are judged by."""
     import numpy as np
     from oracle import oracle as orc
     assert step.world == 1
     dev = step.x.device
-    cell = step.gen.epoch_dev(dev)
+    cell = step.cell if getattr(step, "cell", None) is not None else step.gen.epoch_dev(dev)
     torch.cuda.synchronize(dev)
-    e_dev = int(cell[0].item())                     # the epoch this replay's launches will read
-    out = step.run()
-    torch.cuda.synchronize(dev)
+    if replay:
+        e_dev = int(cell[0].item())                 # the epoch this replay's launches will read
+        out = step.run()
+        torch.cuda.synchronize(dev)
+        e_after = int(cell[0].item())
+    else:
+        e_after = int(cell[0].item())
+        e_dev = e_after - 1                         # the epoch the last replay read (it bumped the word at its end)
+        out = step.packed
     got = out.detach().float().cpu().numpy().copy()
-    e_after = int(cell[0].item())
     S, T = step.samples, step.T
     rnd = orc.bf16_round if mode == "bf16" else (lambda a: np.asarray(a, np.float32))
     h0 = rnd(x_cpu[:rows].float().numpy())
@@ -642,6 +696,8 @@ def main(argv=None):
     ap.add_argument("--mode", default="forward", choices=["forward", "train"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1 headline: strong = the 8 global MC samples sharded 8/N per GPU (SURVEY 8e); weak = 8 per GPU")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BNN_BENCH_INFLIGHT", "3")),
+                    help="N = 1 forward: independent steps in flight on separate streams (1 = one stream)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the configs[2..4] / K1 / K3 roofline legs")
@@ -681,7 +737,7 @@ def main(argv=None):
     bnn.manual_seed(2)
 
     strong = world > 1 and args.scaling == "strong" and SAMPLES % world == 0
-    results, checked, weak = {}, None, None
+    results, checked, weak, pipeline = {}, None, None, None
     for mode in ([args.dtype] + (["f32"] if (args.dtype != "f32" and world == 1) else [])):
         bnn.set_compute(mode)
         # bf16 mode: the synthetic batch is resident in HBM as bf16 (the first layer would round its
@@ -697,6 +753,22 @@ def main(argv=None):
         results[mode] = ((SAMPLES if strong else world * SAMPLES) * steps / dt, dt / steps * 1e3, steps)
         if mode == args.dtype and world == 1:
             checked = oracle_check(step, post, x_cpu, mode)
+            if args.inflight > 1 and not args.no_graph and args.mode == "forward":
+                # throughput pipeline: `inflight` steps on as many streams; the single-stream number above becomes the latency
+                single = results[mode]
+                pipe = PipelinedSteps(net, x_in, args.inflight)
+                pdt = time_steps(pipe, steps, args.warmup, world, dev)
+                # what the steps' LAST replays -- executed while the others were in flight -- left behind, against the oracle
+                pchks = [oracle_check(st, post, x_cpu, mode, replay=False) for st in pipe.steps]
+                results[mode] = (SAMPLES * steps / pdt, pdt / steps * 1e3, steps)
+                pipeline = {"steps_in_flight": args.inflight, "single_stream_value": round(single[0], 1),
+                            "single_stream_ms_per_step": round(single[1], 4),
+                            "checked_in_flight_results_ok": all(c["ok"] for c in pchks),
+                            "in_flight_pred_max_err": max(c["pred_max_err"] for c in pchks),
+                            "in_flight_epochs": [c["epoch_dev"] for c in pchks],
+                            "note": "value / ms_per_step are the pipelined THROUGHPUT (K complete steps / wall time); one "
+                                    "step's latency is single_stream_ms_per_step"}
+                del pipe
         if mode == args.dtype and strong:
             wstep = Step(net, x_in, rank, world, not args.no_graph)
             wdt = time_steps(wstep, steps, args.warmup, world, dev)
@@ -739,6 +811,8 @@ def main(argv=None):
                             "note": "weak scaling: 8 MC samples on every GPU (global predictive mean over 8 N)"}
         if checked is not None:
             line["checked"] = checked
+        if pipeline is not None:
+            line["config"]["pipeline"] = pipeline
         if train is not None:
             line["train"] = {"value": round(train[0], 1), "unit": "MC-samples/s", "ms_per_step": round(train[1], 4),
                              "steps": train[2], "loss": round(train[3], 4), "hip_graph": (not args.no_graph) and world == 1,

@@ -95,3 +95,40 @@ def test_timed_graph_replays_match_oracle(mode):
         h.remove()
         bnn.set_compute("f32")
         step.gen.epoch_dev(dev).zero_()         # later tests address draws with epoch_dev = 0
+
+
+@pytest.mark.gpu
+def test_pipelined_steps_in_flight_match_oracle():
+    """bench.PipelinedSteps: independent captured steps replayed round-robin on separate streams (what the N = 1 headline
+    times).  After 7 replays the result each step's LAST replay left behind -- computed while the other step was in flight
+    -- is checked against the oracle on that replay's epoch; the steps own their epoch words, so they never draw the same
+    noise."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import bayesianneuralnetworks_amd as bnn
+    dev = torch.device("cuda:0")
+    post = bench.posteriors(0)
+    net = bench.build_net(dev, post)
+    x_cpu = torch.randn(bench.BATCH, bench.DIMS[0], generator=torch.Generator().manual_seed(1))
+    bnn.manual_seed(2)
+    bnn.set_compute("bf16")
+    try:
+        pipe = bench.PipelinedSteps(net, bench.resident_input(x_cpu.to(dev), "bf16"), 2)
+        for _ in range(7):
+            pipe.run()
+        pipe.finish()
+        torch.cuda.synchronize()
+        outs = []
+        for st in pipe.steps:
+            res = bench.oracle_check(st, post, x_cpu, "bf16", replay=False)
+            print(json.dumps(res))
+            assert res["ok"] and res["kl_rel_err"] <= 1e-5, res
+            outs.append(st.packed.detach().cpu().numpy().copy())
+        # 7 replays dealt 4 + 3, on top of the two eager warm-up runs each capture makes
+        assert [int(st.cell[0].item()) for st in pipe.steps] == [2 + 4, 2 + 3]
+        assert np.abs(outs[0][pipe.steps[0].T + 1:] - outs[1][pipe.steps[1].T + 1:]).max() > 1e-3
+        # the device-wide epoch word was not touched by the private steps
+        from bayesianneuralnetworks_amd._rng import default_generator
+        assert int(default_generator.epoch_dev(dev)[0].item()) == 0
+    finally:
+        bnn.set_compute("f32")
