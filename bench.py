@@ -255,25 +255,29 @@ class PipelinedSteps:
     ingest / MFMA-bound).  A serving-style throughput pipeline: every step is still one complete stochastic forward + KL +
     predictive mean over one batch; its latency is that of the single-stream step (reported next to the throughput)."""
 
-    def __init__(self, net, x, depth):
+    def __init__(self, net, x, depth, rank=0, world=1, **step_kw):
         dev = x.device
         self.dev = dev
-        self.steps = [Step(net, x, 0, 1, True, private=True) for _ in range(depth)]
+        self.steps = [Step(net, x, rank, world, True, private=True, **step_kw) for _ in range(depth)]
         self.streams = [torch.cuda.Stream(dev) for _ in range(depth)]
         self.i = 0
-        self.world = 1
+        self.world = world
         cur = torch.cuda.current_stream(dev)
         for st in self.streams:
             st.wait_stream(cur)
 
     def run(self):
+        """Replay the next step on its stream.  N > 1: Step.run also issues that step's one all-reduce (asynchronous, on the
+        step's own communication buffer; every rank issues the collectives in the same round-robin order)."""
         k = self.i % len(self.steps)
         self.i += 1
         with torch.cuda.stream(self.streams[k]):
-            self.steps[k].graph.replay()
-        return self.steps[k].packed
+            return self.steps[k].run()
 
     def finish(self):
+        for k, st in enumerate(self.steps):
+            with torch.cuda.stream(self.streams[k]):
+                st.finish()
         cur = torch.cuda.current_stream(self.dev)
         for st in self.streams:
             cur.wait_stream(st)
@@ -743,34 +747,40 @@ def main(argv=None):
         # bf16 mode: the synthetic batch is resident in HBM as bf16 (the first layer would round its
         # A operand to bf16 anyway -- identical results, half the input stream); fp32 mode: fp32.
         x_in = resident_input(x, mode)
+        use_pipe = args.inflight > 1 and not args.no_graph and args.mode == "forward" and mode == args.dtype
+        skw = {}
         if strong:
             s0, cnt = bd.shard_samples(SAMPLES, rank, world)
-            step = Step(net, x_in, rank, world, not args.no_graph, samples=cnt, sample0=s0, total_samples=SAMPLES)
-        else:
-            step = Step(net, x_in, rank, world, not args.no_graph)
+            skw = dict(samples=cnt, sample0=s0, total_samples=SAMPLES)
+        step = Step(net, x_in, rank, world, not args.no_graph, **skw)
         steps = args.steps if mode == args.dtype else max(10, args.steps // 4)
+        total = SAMPLES if strong else world * SAMPLES
         dt = time_steps(step, steps, args.warmup, world, dev)
-        results[mode] = ((SAMPLES if strong else world * SAMPLES) * steps / dt, dt / steps * 1e3, steps)
+        results[mode] = (total * steps / dt, dt / steps * 1e3, steps)
         if mode == args.dtype and world == 1:
             checked = oracle_check(step, post, x_cpu, mode)
-            if args.inflight > 1 and not args.no_graph and args.mode == "forward":
-                # throughput pipeline: `inflight` steps on as many streams; the single-stream number above becomes the latency
-                single = results[mode]
-                pipe = PipelinedSteps(net, x_in, args.inflight)
-                pdt = time_steps(pipe, steps, args.warmup, world, dev)
+        if use_pipe:
+            # throughput pipeline: `inflight` steps on as many streams; the single-stream number above becomes the latency
+            single = results[mode]
+            pipe = PipelinedSteps(net, x_in, args.inflight, rank, world, **skw)
+            pdt = time_steps(pipe, steps, args.warmup, world, dev)
+            results[mode] = (total * steps / pdt, pdt / steps * 1e3, steps)
+            pipeline = {"steps_in_flight": args.inflight, "single_stream_value": round(single[0], 1),
+                        "single_stream_ms_per_step": round(single[1], 4),
+                        "note": "value / ms_per_step are the pipelined THROUGHPUT (K complete steps / wall time); one "
+                                "step's latency is single_stream_ms_per_step"}
+            if world == 1:
                 # what the steps' LAST replays -- executed while the others were in flight -- left behind, against the oracle
                 pchks = [oracle_check(st, post, x_cpu, mode, replay=False) for st in pipe.steps]
-                results[mode] = (SAMPLES * steps / pdt, pdt / steps * 1e3, steps)
-                pipeline = {"steps_in_flight": args.inflight, "single_stream_value": round(single[0], 1),
-                            "single_stream_ms_per_step": round(single[1], 4),
-                            "checked_in_flight_results_ok": all(c["ok"] for c in pchks),
-                            "in_flight_pred_max_err": max(c["pred_max_err"] for c in pchks),
-                            "in_flight_epochs": [c["epoch_dev"] for c in pchks],
-                            "note": "value / ms_per_step are the pipelined THROUGHPUT (K complete steps / wall time); one "
-                                    "step's latency is single_stream_ms_per_step"}
-                del pipe
+                pipeline.update({"checked_in_flight_results_ok": all(c["ok"] for c in pchks),
+                                 "in_flight_pred_max_err": max(c["pred_max_err"] for c in pchks),
+                                 "in_flight_epochs": [c["epoch_dev"] for c in pchks]})
+            del pipe
         if mode == args.dtype and strong:
-            wstep = Step(net, x_in, rank, world, not args.no_graph)
+            if use_pipe:
+                wstep = PipelinedSteps(net, x_in, args.inflight, rank, world)
+            else:
+                wstep = Step(net, x_in, rank, world, not args.no_graph)
             wdt = time_steps(wstep, steps, args.warmup, world, dev)
             weak = (world * SAMPLES * steps / wdt, wdt / steps * 1e3)
             del wstep

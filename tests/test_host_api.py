@@ -133,6 +133,38 @@ def test_kl_divergence_convenience_methods():
     assert bnn.nn.BayesianConv2d is NormalConv2d
 
 
+def test_draw_once_entry_points_reject_bad_arguments_without_launching():
+    """bnn_draw_multi / bnn_dense_forward / bnn_conv2d_dense_forward / bnn_conv2d_flipout_forward: argument errors are
+    negative codes with a message before anything touches the GPU (runs without one)."""
+    lib = _lib.load()
+    n0 = lib.bnn_launch_count()
+    one = ctypes.c_void_p(16)
+    t = (_lib.DrawTensor * 1)()
+    t[0].mu, t[0].rho, t[0].out, t[0].rows, t[0].cols, t[0].ld, t[0].out_sample_stride = 16, 16, 16, 4, 8, 64, 256
+    t[0].out_dtype, t[0].rng.seed, t[0].rng.stream = _lib.BF16, 1, 1
+    assert lib.bnn_draw_multi(None, 1, 1, None, 0, None, None) == -1
+    assert lib.bnn_draw_multi(t, 9, 1, None, 0, None, None) == -5                       # > 8 tensors per launch
+    t[0].cols = 6                                                                        # rows > 1 need cols % 4 == 0
+    assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == _lib.E_UNSUPPORTED and b"cols" in lib.bnn_last_error()
+    t[0].cols, t[0].rng.stream = 8, 70000
+    assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == -5                       # stream id out of range
+    t[0].rng.stream, t[0].kind = 1, 3
+    assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == -5 and b"kind" in lib.bnn_last_error()
+    # dense: weights must be zero-padded to a multiple of 64 columns; K % 8 == 0
+    assert lib.bnn_dense_forward(one, 0, 72, one, 16 * 72, 72, None, 0, one, 64, 16, 4, 16, 72, 1, 0, None) == _lib.E_UNSUPPORTED
+    assert b"roundup" in lib.bnn_last_error()
+    assert lib.bnn_dense_forward(None, 0, 64, one, 0, 64, None, 0, one, 64, 16, 4, 16, 64, 1, 0, None) == -1
+    assert lib.bnn_dense_forward(one, 0, 64, one, 0, 64, None, 0, one, 64, 16, 4, 16, 64, 1, 64, None) == _lib.E_UNSUPPORTED   # unknown flag
+    sh = _lib.Conv2dShape(B=2, C=48, H=6, W=6, O=64, KH=3, KW=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, dil_h=1, dil_w=1, groups=1)
+    assert lib.bnn_conv2d_dense_forward(one, 0, one, 0, 448, None, 0, one, 0, ctypes.byref(sh), 1, 0, None) == _lib.E_UNSUPPORTED
+    assert b"C = 64" in lib.bnn_last_error()
+    sh.C = 64
+    assert lib.bnn_conv2d_flipout_forward(one, one, 576, None, one, one, ctypes.byref(sh), 0, None) == -1
+    sh.O = 128                                                                           # Flipout: 2 O must be 64 or 128
+    assert lib.bnn_conv2d_flipout_forward(one, one, 576, one, one, one, ctypes.byref(sh), 0, None) == _lib.E_UNSUPPORTED
+    assert lib.bnn_launch_count() == n0
+
+
 def test_exports_match_reference_names():
     # pytorch_bayesian/nn/__init__.py:7-35
     names = ['BayesianModule', 'BayesianNetworkModule', 'WeightNormal', 'WeightMultivariateNormal',
