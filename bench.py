@@ -227,6 +227,14 @@ class Step:
         self.graph = g
 
     def run(self):
+        if self.world > 1 and self.private:
+            # one of several steps in flight (PipelinedSteps): its buffer is not touched by the other steps, so the all-reduce
+            # runs IN PLACE on `packed` -- this step's next replay (depth iterations later, on this stream) waits for it first
+            if self.pending is not None:
+                self.pending.wait()
+            self.graph.replay() if self.graph is not None else self._body()
+            self.pending = torch.distributed.all_reduce(self.packed, async_op=True)
+            return self.packed
         if self.graph is not None:
             self.graph.replay()
         else:

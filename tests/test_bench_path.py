@@ -132,3 +132,42 @@ def test_pipelined_steps_in_flight_match_oracle():
         assert int(default_generator.epoch_dev(dev)[0].item()) == 0
     finally:
         bnn.set_compute("f32")
+
+
+@pytest.mark.gpu
+def test_strong_scaling_shards_reproduce_the_single_gpu_step():
+    """What `bench.py --gpus G` runs on rank r (S / G samples, global ids from r S / G; KL slice r of G) -- executed here rank
+    after rank on one GPU, the all-reduce replaced by a sum -- gives the single-GPU 8-sample step: the eps stream is addressed
+    by the GLOBAL sample id, so the union of the ranks' draws does not depend on G.  Covers the 4-, 2- and 1-sample launches
+    of the draw / dense kernels that the driver's 2-, 4- and 8-GPU runs use."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd import distributed as bd
+    dev = torch.device("cuda:0")
+    post = bench.posteriors(0)
+    net = bench.build_net(dev, post)
+    x = bench.resident_input(torch.randn(bench.BATCH, bench.DIMS[0], generator=torch.Generator().manual_seed(1)).to(dev), "bf16")
+    bnn.set_compute("bf16")
+    try:
+        bnn.manual_seed(2)
+        full = bench.Step(net, x, 0, 1, True)
+        ref = full.packed.detach().cpu().numpy().copy()           # result of the capture's own first replay (epoch_dev = 2)
+        T = full.T
+        for G in (2, 4, 8):
+            acc = np.zeros_like(ref)
+            for r in range(G):
+                s0, cnt = bd.shard_samples(bench.SAMPLES, r, G)
+                bnn.manual_seed(2)                                 # same host epochs -> the same draw keys as `full`
+                st = bench.Step(net, x, r, G, True, samples=cnt, sample0=s0, total_samples=bench.SAMPLES)
+                torch.cuda.synchronize()
+                acc += st.packed.detach().cpu().numpy()
+                del st
+            # predictions: sum over ranks of (1 / 8) sum over local samples == the 8-sample mean (fp32 sums in another order)
+            assert np.abs(acc[T + 1:] - ref[T + 1:]).max() <= 1e-4 * max(1.0, float(np.abs(ref[T + 1:]).max())), G
+            # KL: per-tensor SUMS add up over the ranks' slices
+            assert np.allclose(acc[:T], ref[:T], rtol=1e-5), G
+    finally:
+        bnn.set_compute("f32")
+        from bayesianneuralnetworks_amd._rng import default_generator
+        default_generator.epoch_dev(dev).zero_()
