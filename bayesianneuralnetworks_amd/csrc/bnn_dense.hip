@@ -215,30 +215,40 @@ __device__ __forceinline__ void dma_piece(const void *base, uint32_t voff, uint3
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds) : "memory");
 }
 
-// ROLE split (8 waves): waves 0-3 consume (fragment reads + MFMA + epilogue), waves 4-7 load.  Loader i fills consumer
-// i's private A ring and a quarter of the shared B tile; one s_barrier per 64-k step, met by all eight waves, is the
-// only hand-off: at barrier t the loaders have waited for THEIR pieces of step t (counted vmcnt: step t + 1's stay in
-// flight) and the consumers have finished step t - 1, whose stage the loaders refill right after the barrier with
-// step t + 2.  The DMA issue stream (~5 instructions per 1-KiB piece) thus runs on the SIMD's second wave beside the
-// MFMA stream instead of in front of it (first version, one role: DMA-only 16.6 us, MFMA-only 18.8 us, together 26.8 us).
+// ROLE split (8 waves): waves 0-3 consume (fragment reads + MFMA + epilogue), waves 4-7 load.  The consumers form an
+// NWM x NWN grid of (16 TM) x (16 TN) wave tiles; a stage of the ring is the workgroup's A rows followed by its B rows
+// (128-B rows, XOR-swizzled 16-B chunks), cut into 1-KiB pieces that loader i takes round-robin (piece q = i + 4 j).
+// One s_barrier per 64-k step, met by all eight waves, is the only hand-off: at barrier t the loaders have waited for
+// THEIR pieces of step t (counted vmcnt: the later steps' stay in flight) and the consumers have finished step t - 1,
+// whose stage the loaders refill right after the barrier with step t + ST - 1.  The DMA issue stream (~5 instructions
+// per 1-KiB piece) thus runs on the SIMD's second wave beside the MFMA stream instead of in front of it (first version,
+// one role: DMA-only 16.6 us, MFMA-only 18.8 us, together 26.8 us).
+//   <4, 5, 4, 1, 3>: 256 x 80 tile, 42 KiB per step, 3 stages (126 KiB)
+//   <4, 5, 2, 2, 4>: 128 x 160 tile, 36 KiB per step for the same 40 MFMAs per wave, 4 stages (144 KiB) -- the BASELINE
+//                    layers: 4 x 8 x 8 = 256 workgroups (N = 1200 rounds up to 1280: the clamped rows are never stored)
+//   <4, 8, 4, 1, 3>: 256 x 128 tile for wide layers
 // DIAG (BNN_DENSE_DIAG, timing-only builds whose outputs are wrong): 1 = consumers skip reads and MFMAs, 2 = loaders skip the DMA.
-template <int TM, int TN, bool YBF, bool RELU, int DIAG = 0>
+template <int TM, int TN, int NWM, int NWN, int ST, bool YBF, bool RELU, int DIAG = 0>
 __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
 {
     constexpr int NWV = 4;                              // consumer waves = loader waves
-    constexpr int WM = 16 * TM, BM = NWV * WM, BN = 16 * TN;
-    constexpr int ST = 3;                               // ring stages
-    constexpr int A_PIECES = WM / 8;                    // 1-KiB pieces (8 rows x 128 B) per consumer per stage
-    constexpr int B_TOTAL = BN / 8;                     // pieces of the shared B tile per stage
+    constexpr bool INTERLEAVE = true;
+    static_assert(NWM * NWN == NWV, "four consumer waves");
+    constexpr int WM = 16 * TM, WN = 16 * TN, BM = NWM * WM, BN = NWN * WN;
+    constexpr int A_TOTAL = BM / 8;                     // 1-KiB pieces (8 rows x 128 B) of the A rows per stage
+    constexpr int B_TOTAL = BN / 8;
+    static_assert(A_TOTAL % NWV == 0, "A pieces divide evenly over the loaders");
+    constexpr int A_PIECES = A_TOTAL / NWV;
     constexpr int B_BASE = B_TOTAL / NWV, B_EXTRA = B_TOTAL % NWV;   // loader i issues B_BASE (+1 if i < B_EXTRA)
-    constexpr int A_STAGE = WM * 128;                   // bytes
+    constexpr int A_STAGE = BM * 128;                   // bytes
     constexpr int B_STAGE = BN * 128;
-    constexpr int A_RING = ST * A_STAGE;
-    // epilogue staging: EPI_A 16-row blocks of the wave's output tile fit its A ring at a time
+    constexpr int STAGE = A_STAGE + B_STAGE;
+    // epilogue staging (after the final barrier): EPI_A 16-row blocks of the wave's output tile at a time in its quarter of the ring
     constexpr int ESZ = YBF ? 2 : 4;
-    constexpr int EPI_A = (A_RING / (16 * BN * ESZ)) < TM ? (A_RING / (16 * BN * ESZ)) : TM;
-    static_assert(EPI_A >= 1, "the wave's A ring must hold at least 16 output rows (epilogue staging)");
-    __shared__ __attribute__((aligned(16))) char lds[NWV * A_RING + ST * B_STAGE];
+    constexpr int EPI_BYTES = ST * STAGE / NWV;
+    constexpr int EPI_A = (EPI_BYTES / (16 * WN * ESZ)) < TM ? (EPI_BYTES / (16 * WN * ESZ)) : TM;
+    static_assert(EPI_A >= 1, "a quarter of the ring must hold at least 16 output rows (epilogue staging)");
+    __shared__ __attribute__((aligned(16))) char lds[ST * STAGE];
 
     // ---- block decode: sample -> XCD when the samples fill the 8 XCDs
     const int per_s = p.ntm * p.ntn;
@@ -259,13 +269,11 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nk = (p.K + 63) / 64;
-    char *b_ring = lds + NWV * A_RING;
 
     if (wave >= NWV) {
         // =============================== loader ===============================
         const int lw = wave - NWV;
-        const uint32_t a_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(lds + lw * A_RING));
-        const uint32_t b_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(b_ring));
+        const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
         // Lane l writes position l & 7 of row l >> 3 of its piece and therefore fetches chunk (l & 7) ^ (l >> 3) of
         // that row (the image's XOR swizzle, applied on the source address).
         const int prow = lane >> 3;
@@ -275,13 +283,13 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
         uint32_t a_off[A_PIECES], b_off[B_BASE + 1];
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j) {
-            int m = m0 + lw * WM + 8 * j + prow;
+            int m = m0 + (lw + NWV * j) * 8 + prow;     // piece q = lw + 4 j of the A rows
             m = m < p.M ? m : p.M - 1;                  // rows >= M: clamped, results never stored
             a_off[j] = (uint32_t)((int64_t)m * p.lda * 2);
         }
 #pragma unroll
         for (int j = 0; j < B_BASE + 1; ++j) {
-            int n = n0 + (lw + NWV * j) * 8 + prow;     // piece q = lw + 4 j of the tile
+            int n = n0 + (lw + NWV * j) * 8 + prow;     // piece q = lw + 4 j of the B rows
             n = n < p.N ? n : p.N - 1;                  // rows >= N: clamped, results never stored
             b_off[j] = (uint32_t)((int64_t)n * p.ldw * 2) + 16u * (uint32_t)schunk;
         }
@@ -295,22 +303,27 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
                 const uint32_t colA0 = (uint32_t)(kt * 128 + 16 * schunk);
                 const uint32_t colA = colA0 < a_colmax ? colA0 : a_colmax;   // k >= K: any finite chunk (the weights are 0 there)
                 const uint32_t colB = (uint32_t)(kt * 128);
+                const uint32_t sb = ring + (uint32_t)(stage * STAGE + lw * 1024);
 #pragma unroll
                 for (int j = 0; j < A_PIECES; ++j)
-                    dma_piece(a_base, a_off[j] + colA, a_lds + (uint32_t)(stage * A_STAGE + j * 1024));
+                    dma_piece(a_base, a_off[j] + colA, sb + (uint32_t)(NWV * j * 1024));
 #pragma unroll
                 for (int j = 0; j < NBP; ++j)
-                    dma_piece(w_base, b_off[j] + colB, b_lds + (uint32_t)(stage * B_STAGE + (lw + NWV * j) * 1024));
+                    dma_piece(w_base, b_off[j] + colB, sb + (uint32_t)(A_STAGE + NWV * j * 1024));
             };
-            issue(0);
-            if (nk > 1) issue(1);
+#pragma unroll
+            for (int i = 0; i < ST - 1; ++i)
+                if (i < nk) issue(i);
             for (int kt = 0; kt < nk; ++kt) {
-                // this wave's pieces of step kt have landed (step kt + 1's P pieces may still be in flight)
-                if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
+                // this wave's pieces of step kt have landed (the later steps' pieces may still be in flight)
+                const int ahead = nk - 1 - kt < ST - 2 ? nk - 1 - kt : ST - 2;
+                if (ST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * P) : "memory");
+                else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();           // barrier kt: stage kt complete; stage (kt + 2) % 3 = (kt - 1) % 3 is free
-                if (kt + 2 < nk) issue(kt + 2);
+                __builtin_amdgcn_s_barrier();           // barrier kt: stage kt complete; stage (kt - 1) % ST is free
+                if (kt + ST - 1 < nk) issue(kt + ST - 1);
             }
+            __builtin_amdgcn_s_barrier();               // final barrier: the consumers reuse the ring for the epilogue
         };
         if (lw < B_EXTRA) run(std::integral_constant<int, B_BASE + 1>{});
         else run(std::integral_constant<int, B_BASE>{});
@@ -318,8 +331,11 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     }
 
     // =============================== consumer ===============================
+    static_assert(ST == 3 || ST == 4, "ring depth");
     const int fi = lane & 15, fq = lane >> 4;
-    char *a_ring = lds + wave * A_RING;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const char *a_rows = lds + wm * WM * 128;               // + stage * STAGE
+    const char *b_rows = lds + A_STAGE + wn * WN * 128;
     __builtin_amdgcn_s_setprio(1);                      // the MFMA stream goes first on its SIMD
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -338,8 +354,8 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     auto rd = [&](auto buf_c, auto stage_c, auto h_c) {
         constexpr int buf = decltype(buf_c)::value, stage = decltype(stage_c)::value, h = decltype(h_c)::value;
         if constexpr (DIAG == 1) return;
-        const char *As = a_ring + stage * A_STAGE + (h ? fbase1 : fbase0);
-        const char *Bs = b_ring + stage * B_STAGE + (h ? fbase1 : fbase0);
+        const char *As = a_rows + stage * STAGE + (h ? fbase1 : fbase0);
+        const char *Bs = b_rows + stage * STAGE + (h ? fbase1 : fbase0);
 #pragma unroll
         for (int b = 0; b < TN; ++b) fb[buf][b] = *reinterpret_cast<const uint4 *>(Bs + b * 2048);
 #pragma unroll
@@ -357,19 +373,38 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // Within a phase the fragment reads are interleaved into the MFMA stream, one ds_read_b128 behind each of the first
+    // TM + TN MFMAs: a read issued in an MFMA's shadow costs no issue time, and none is needed before the next phase
+    // (block scheduling: the reads-then-MFMAs order cost ~250 cycles of a 900-cycle step with the MFMA pipe idle).
+    auto interleave = [&]() {
+        if constexpr (DIAG == 0 && INTERLEAVE) {
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+        }
+    };
     auto step = [&](auto stage_c, auto next_c, bool more) {
         rd(I1{}, stage_c, I1{});                        // (t, h1) -> buffer 1
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
         mm(I0{});                                       // (t, h0)
+        interleave();
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of stage t have returned
             __builtin_amdgcn_s_barrier();               // barrier t + 1
             asm volatile("" ::: "memory");
             rd(I0{}, next_c, I0{});                     // (t + 1, h0) -> buffer 0
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+            mm(I1{});                                   // (t, h1)
+            interleave();
+        } else {
+            mm(I1{});
         }
-        mm(I1{});                                       // (t, h1)
         __builtin_amdgcn_sched_barrier(0);
     };
     __builtin_amdgcn_s_barrier();                       // barrier 0
@@ -377,29 +412,36 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     rd(I0{}, I0{}, I0{});
     for (int kt = 0; kt < nk; kt += ST) {
         step(I0{}, I1{}, kt + 1 < nk);
-        if (kt + 1 < nk) step(I1{}, std::integral_constant<int, 2>{}, kt + 2 < nk);
-        if (kt + 2 < nk) step(std::integral_constant<int, 2>{}, I0{}, kt + 3 < nk);
+        if (kt + 1 < nk) step(I1{}, I2{}, kt + 2 < nk);
+        if constexpr (ST == 3) {
+            if (kt + 2 < nk) step(I2{}, I0{}, kt + 3 < nk);
+        } else {
+            if (kt + 2 < nk) step(I2{}, I3{}, kt + 3 < nk);
+            if (kt + 3 < nk) step(I3{}, I0{}, kt + 4 < nk);
+        }
     }
     __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // final barrier: every wave's last fragment read is behind it
+    asm volatile("" ::: "memory");
 
     // ---- epilogue: bias, activation, store (accumulator lane (i, q), register r = row 4 q + r, column i of a 16 x 16 block)
     const float *bias = p.bias ? p.bias + (int64_t)s * p.bias_sample_stride : nullptr;
     const int64_t ybase = (int64_t)s * p.y_sample_stride * ESZ;
-    const int mw = m0 + wave * WM;
+    const int mw = m0 + wm * WM, nw = n0 + wn * WN;
     float bv[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int n = n0 + b * 16 + fi;
+        const int n = nw + b * 16 + fi;
         bv[b] = (bias && n < p.N) ? bias[n] : 0.f;
     }
-    const bool wide = n0 + BN <= p.N && mw + WM <= p.M && (p.ldy * ESZ) % 16 == 0 && (n0 * ESZ) % 16 == 0 &&
+    const bool wide = nw + WN <= p.N && mw + WM <= p.M && (p.ldy * ESZ) % 16 == 0 && (nw * ESZ) % 16 == 0 &&
                       ((reinterpret_cast<uintptr_t>(p.Y) + ybase) & 15u) == 0;
     if (wide) {
-        // this wave's last read of its A ring is behind it (its MFMAs have their operands) and no loader writes it again
-        char *T = a_ring;
-        constexpr int pitch = BN * ESZ;
+        char *T = lds + wave * EPI_BYTES;
+        constexpr int pitch = WN * ESZ;
         constexpr int cpr = pitch / 16;
-        char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)mw * p.ldy + n0) * ESZ;
+        char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)mw * p.ldy + nw) * ESZ;
 #pragma unroll
         for (int a0 = 0; a0 < TM; a0 += EPI_A) {
 #pragma unroll
@@ -431,7 +473,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     uint16_t *Yh = reinterpret_cast<uint16_t *>(p.Y) + (int64_t)s * p.y_sample_stride;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int n = n0 + b * 16 + fi;
+        const int n = nw + b * 16 + fi;
         if (n >= p.N) continue;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -843,7 +885,10 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
     int split = 1;
     while (split < nsamples && (int64_t)L.draw_blocks * split < 1024) split *= 2;
     if (split > nsamples) split = nsamples;
-    hipLaunchKernelGGL(k_draw_multi<1>, dim3((unsigned)grid, (unsigned)split), dim3(256), 0, (hipStream_t)stream, L);
+    static const int force_split = [] { const char *e = getenv("BNN_DRAW_SPLIT"); return e ? atoi(e) : 0; }();
+    if (force_split >= 1 && force_split <= nsamples) split = force_split;
+    static const int dyn_lds = [] { const char *e = getenv("BNN_DRAW_LDS"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(k_draw_multi<1>, dim3((unsigned)grid, (unsigned)split), dim3(256), (size_t)dyn_lds, (hipStream_t)stream, L);
     return check_launch(who);
 }
 
@@ -880,34 +925,39 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
         hipLaunchKernelGGL(k_head_bf16, dim3((unsigned)((int64_t)p.ntm * nsamples)), dim3(256), 0, st, p);
         return check_launch(who);
     }
-    static const int force_tn = [] { const char *e = getenv("BNN_DENSE_TN"); return e ? atoi(e) : 0; }();
     static const bool no_xcd = [] { const char *e = getenv("BNN_DENSE_XCD"); return e && e[0] == '0'; }();
     if (no_xcd) p.flags |= kDenseNoXcdMap;
-    // tile: 256 rows x 16 TN columns.  TN = 5 (80 columns) divides the BASELINE width 1200 exactly: 2 x 15 x 8 = 240
-    // workgroups on 256 CUs; wide layers take 128 columns.
-    int tn = (N % 80 == 0 || N < 128) ? 5 : 8;
-    if (force_tn == 5 || force_tn == 8) tn = force_tn;
-    const int bn = 16 * tn;
-    p.ntm = (int32_t)((M + 255) / 256);
+    // tile: the BASELINE-shaped layers (N % 80 == 0: 1200 = 7.5 x 160) take 128 x 160 with a 4-stage ring -- 36 KiB per
+    // 64-k step instead of 256 x 80's 42 for the same MFMAs, 4 x 8 x 8 = 256 workgroups; wide layers 256 x 128.
+    // BNN_DENSE_TILE = 0 (256 x 80), 1 (128 x 160), 2 (256 x 128) forces one for A/B runs.
+    static const int force_tile = [] { const char *e = getenv("BNN_DENSE_TILE"); return e ? atoi(e) : -1; }();
+    int tile = (N % 80 == 0 || N < 128) ? 1 : 2;
+    if (N <= 80) tile = 0;
+    if (force_tile >= 0 && force_tile <= 2) tile = force_tile;
+    const int bm = tile == 1 ? 128 : 256;
+    const int bn = tile == 0 ? 80 : tile == 1 ? 160 : 128;
+    p.ntm = (int32_t)((M + bm - 1) / bm);
     p.ntn = (int32_t)((N + bn - 1) / bn);
     const int64_t grid = (int64_t)p.ntm * p.ntn * nsamples;
     if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
     static const int diag = [] { const char *e = getenv("BNN_DENSE_DIAG"); return e ? atoi(e) : 0; }();
     const bool relu = (flags & BNN_FLAG_RELU) != 0;
     const dim3 g((unsigned)grid), blk(512);
-#define BNN_DENSE_LAUNCH(TN_, YBF_, RELU_) \
+#define BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, YBF_, RELU_) \
     do { \
-        if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<4, TN_, YBF_, RELU_, 1>), g, blk, 0, st, p); \
-        else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<4, TN_, YBF_, RELU_, 2>), g, blk, 0, st, p); \
-        else hipLaunchKernelGGL((k_dense_bf16<4, TN_, YBF_, RELU_>), g, blk, 0, st, p); \
+        if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 1>), g, blk, 0, st, p); \
+        else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 2>), g, blk, 0, st, p); \
+        else hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_>), g, blk, 0, st, p); \
     } while (0)
-    if (tn == 5) {
-        if (ybf) { if (relu) BNN_DENSE_LAUNCH(5, true, true); else BNN_DENSE_LAUNCH(5, true, false); }
-        else { if (relu) BNN_DENSE_LAUNCH(5, false, true); else BNN_DENSE_LAUNCH(5, false, false); }
-    } else {
-        if (ybf) { if (relu) BNN_DENSE_LAUNCH(8, true, true); else BNN_DENSE_LAUNCH(8, true, false); }
-        else { if (relu) BNN_DENSE_LAUNCH(8, false, true); else BNN_DENSE_LAUNCH(8, false, false); }
-    }
+#define BNN_DENSE_PICK(TN_, NWM_, NWN_, ST_) \
+    do { \
+        if (ybf) { if (relu) BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, true, true); else BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, true, false); } \
+        else { if (relu) BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, false, true); else BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, false, false); } \
+    } while (0)
+    if (tile == 0) BNN_DENSE_PICK(5, 4, 1, 3);
+    else if (tile == 1) BNN_DENSE_PICK(5, 2, 2, 4);
+    else BNN_DENSE_PICK(8, 4, 1, 3);
+#undef BNN_DENSE_PICK
 #undef BNN_DENSE_LAUNCH
     return check_launch(who);
 }

@@ -445,11 +445,12 @@ class _SampledLinear(torch.autograd.Function):
     into its epilogue (csrc/bnn_linear_bwd.hip)."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute, relu, out_dtype, predrawn=None):
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute, relu, out_dtype, predrawn=None, track=True):
         # x: (M, K) shared by all samples, or (S, M, K), fp32 or (bf16 compute mode) bf16;
         # relu: max(., 0) fused in the epilogue; out_dtype: fp32, or bf16 for a hidden activation
         # x may be a row-padded view (rows_regular) on the inference path; whatever the backward saves is contiguous
-        needs_grad = any(ctx.needs_input_grad[:5])
+        # track: grad mode at the call (inside forward it is always off, and needs_input_grad only mirrors requires_grad)
+        needs_grad = track and any(ctx.needs_input_grad[:5])
         if needs_grad or not (x.dtype == torch.bfloat16 and rows_regular(x, x.shape[-1])):
             x = x.contiguous()
         require_cuda_act(x, "x", contiguous=False)
@@ -508,7 +509,7 @@ class _SampledLinear(torch.autograd.Function):
                 ctypes.byref(rw), ctypes.byref(rb) if rb is not None else None,
                 ctypes.byref(kl) if kl is not None else None, flags, 0, stream_ptr(dev))
             if rc == 0:
-                return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None, None
+                return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None, None, None
             if rc not in (_lib.E_UNSUPPORTED, _lib.E_ALIGN):
                 check(rc, "bnn_linear_backward_narrow_sampled")
             # not applicable here (workspace, alignment): the general kernels below; hand the KL entries back
@@ -557,7 +558,7 @@ class _SampledLinear(torch.autograd.Function):
         elif need_b:
             gb = _colsum_raw(gy)                                           # (S, N)
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
-        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None, None
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None, None, None
 
 
 def linear_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute="f32", relu=False,
@@ -565,7 +566,8 @@ def linear_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, compute=
     return _SampledLinear.apply(x, mu_w.contiguous(), rho_w.contiguous(),
                                 None if mu_b is None else mu_b.contiguous(),
                                 None if rho_b is None else rho_b.contiguous(),
-                                key_w, key_b, shared_x, _compute_code(compute), bool(relu), out_dtype, predrawn)
+                                key_w, key_b, shared_x, _compute_code(compute), bool(relu), out_dtype, predrawn,
+                                torch.is_grad_enabled())
 
 
 class _PlainLinear(torch.autograd.Function):

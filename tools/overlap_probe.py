@@ -1,0 +1,68 @@
+"""Do the draw launch (VALU-bound) and the dense contraction (MFMA / LDS-DMA-bound) overlap when they run on two streams?
+usage: python tools/overlap_probe.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bayesianneuralnetworks_amd import _lib, ops
+from bayesianneuralnetworks_amd._rng import DrawKey
+import bench
+
+lib = _lib.load(); dev = torch.device("cuda:0")
+S, B = 8, 512
+post = [[t.to(dev) for t in p] for p in bench.posteriors(0)]
+layers = [(mw, rw, mb, rb, DrawKey(1, 2 * i + 1, 0, S, 0), DrawKey(1, 2 * i + 2, 0, S, 0)) for i, (mw, rw, mb, rb) in enumerate(post)]
+pre = ops.draw_layers(layers, S)
+h = torch.zeros(S, B, 1216, device=dev, dtype=torch.bfloat16)
+h[:, :, :1200] = torch.randn(S, B, 1200, device=dev).relu_().bfloat16()
+y = torch.empty(S, B, 1216, device=dev, dtype=torch.bfloat16)
+
+
+def gemm():
+    _lib.check(lib.bnn_dense_forward(_lib.ptr(h), B * 1216, 1216, _lib.ptr(pre[1].w), 1200 * 1216, 1216, _lib.ptr(pre[1].b), 1200,
+                                     _lib.ptr(y), B * 1216, 1216, B, 1200, 1200, S, _lib.FLAG_RELU | _lib.FLAG_Y_BF16, _lib.stream_ptr(dev)), "dense")
+
+
+def draw():
+    ops.draw_layers(layers, S)
+
+
+def graph_of(fn, n, stream):
+    with torch.cuda.stream(stream):
+        fn(); fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        for _ in range(n):
+            fn()
+    return g
+
+
+sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+N = 20
+ga = graph_of(draw, N, sa)
+gb = graph_of(gemm, N, sb)
+
+
+def run(pairs, reps=20):
+    for g, s in pairs:
+        with torch.cuda.stream(s):
+            g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for g, s in pairs:
+            with torch.cuda.stream(s):
+                g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps / N * 1e6
+
+
+ta = run([(ga, sa)]); tb = run([(gb, sb)]); tab = run([(ga, sa), (gb, sb)])
+print("draw alone %.2f us, gemm alone %.2f us, both streams together %.2f us per (draw + gemm) pair: serial sum %.2f, perfect overlap %.2f"
+      % (ta, tb, tab, ta + tb, max(ta, tb)))
+gb2 = graph_of(gemm, N, sa)
+tbb = run([(gb, sb), (gb2, sa)])
+print("two gemm streams: %.2f us per pair (alone %.2f each)" % (tbb, tb))
+ga2 = graph_of(draw, N, sb)
+taa = run([(ga, sa), (ga2, sb)])
+print("two draw streams: %.2f us per pair (alone %.2f each)" % (taa, ta))
