@@ -227,12 +227,14 @@ __device__ __forceinline__ void dma_piece(const void *base, uint32_t voff, uint3
 //   <4, 5, 2, 2, 4>: 128 x 160 tile, 36 KiB per step for the same 40 MFMAs per wave, 4 stages (144 KiB) -- the BASELINE
 //                    layers: 4 x 8 x 8 = 256 workgroups (N = 1200 rounds up to 1280: the clamped rows are never stored)
 //   <4, 8, 4, 1, 3>: 256 x 128 tile for wide layers
-// DIAG (BNN_DENSE_DIAG, timing-only builds whose outputs are wrong): 1 = consumers skip reads and MFMAs, 2 = loaders skip the DMA.
+// DIAG (BNN_DENSE_DIAG): timing-only builds whose outputs are wrong: 1 = consumers skip reads and MFMAs, 2 = loaders skip the
+// DMA; correct builds for A/B runs of the read interleave: 3 = one MFMA per interleaved fragment read, 4 = two.
 template <int TM, int TN, int NWM, int NWN, int ST, bool YBF, bool RELU, int DIAG = 0>
 __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
 {
     constexpr int NWV = 4;                              // consumer waves = loader waves
     constexpr bool INTERLEAVE = true;
+    constexpr int MPR = DIAG == 3 ? 1 : DIAG == 4 ? 2 : TN >= 8 ? 2 : 1;                // MFMAs per interleaved fragment read (measured: 64 x 80 wave tile 15.9 / 16.9 us with 1 / 2, 64 x 128 at 4096^3 171 / 140 us)
     static_assert(NWM * NWN == NWV, "four consumer waves");
     constexpr int WM = 16 * TM, WN = 16 * TN, BM = NWM * WM, BN = NWN * WN;
     constexpr int A_TOTAL = BM / 8;                     // 1-KiB pieces (8 rows x 128 B) of the A rows per stage
@@ -281,17 +283,22 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
         const char *a_base = reinterpret_cast<const char *>(p.A + (int64_t)s * p.a_sample_stride);
         const char *w_base = reinterpret_cast<const char *>(p.W + (int64_t)s * p.w_sample_stride);
         uint32_t a_off[A_PIECES], b_off[B_BASE + 1];
+        uint32_t a_dst[A_PIECES], b_dst[B_BASE + 1];    // LDS byte offsets of this wave's pieces within stage 0
 #pragma unroll
         for (int j = 0; j < A_PIECES; ++j) {
-            int m = m0 + (lw + NWV * j) * 8 + prow;     // piece q = lw + 4 j of the A rows
+            const int r0 = (lw + NWV * j) * 8;          // piece q = lw + 4 j of the A rows
+            int m = m0 + r0 + prow;
             m = m < p.M ? m : p.M - 1;                  // rows >= M: clamped, results never stored
             a_off[j] = (uint32_t)((int64_t)m * p.lda * 2);
+            a_dst[j] = (uint32_t)((r0 / WM) * (ST * WM * 128) + (r0 % WM) * 128);
         }
 #pragma unroll
         for (int j = 0; j < B_BASE + 1; ++j) {
-            int n = n0 + (lw + NWV * j) * 8 + prow;     // piece q = lw + 4 j of the B rows
+            const int r0 = (lw + NWV * j) * 8;          // piece q = lw + 4 j of the B rows
+            int n = n0 + r0 + prow;
             n = n < p.N ? n : p.N - 1;                  // rows >= N: clamped, results never stored
             b_off[j] = (uint32_t)((int64_t)n * p.ldw * 2) + 16u * (uint32_t)schunk;
+            b_dst[j] = (uint32_t)(ST * A_STAGE + (r0 / WN) * (ST * WN * 128) + (r0 % WN) * 128);
         }
         const uint32_t a_colmax = (uint32_t)(p.K * 2 - 16);    // last legal 16-B chunk of an activation row
         auto run = [&](auto nbp_c) {
@@ -303,13 +310,13 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
                 const uint32_t colA0 = (uint32_t)(kt * 128 + 16 * schunk);
                 const uint32_t colA = colA0 < a_colmax ? colA0 : a_colmax;   // k >= K: any finite chunk (the weights are 0 there)
                 const uint32_t colB = (uint32_t)(kt * 128);
-                const uint32_t sb = ring + (uint32_t)(stage * STAGE + lw * 1024);
+                const uint32_t sa = ring + (uint32_t)(stage * (WM * 128)), sb = ring + (uint32_t)(stage * (WN * 128));
 #pragma unroll
                 for (int j = 0; j < A_PIECES; ++j)
-                    dma_piece(a_base, a_off[j] + colA, sb + (uint32_t)(NWV * j * 1024));
+                    dma_piece(a_base, a_off[j] + colA, sa + a_dst[j]);
 #pragma unroll
                 for (int j = 0; j < NBP; ++j)
-                    dma_piece(w_base, b_off[j] + colB, sb + (uint32_t)(A_STAGE + NWV * j * 1024));
+                    dma_piece(w_base, b_off[j] + colB, sb + b_dst[j]);
             };
 #pragma unroll
             for (int i = 0; i < ST - 1; ++i)
@@ -334,8 +341,11 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     static_assert(ST == 3 || ST == 4, "ring depth");
     const int fi = lane & 15, fq = lane >> 4;
     const int wm = wave / NWN, wn = wave % NWN;
-    const char *a_rows = lds + wm * WM * 128;               // + stage * STAGE
-    const char *b_rows = lds + A_STAGE + wn * WN * 128;
+    // LDS: [wm][stage][WM rows] for A, then [wn][stage][WN rows] for B -- every fragment of a wave within 64 KiB of its two
+    // bases (the reach of the ds_read immediate); with whole stages laid out one after the other the compiler carries an
+    // extra lane-varying base per far stage and the 256 x 128 tile's accumulators spill
+    const char *a_rows = lds + wm * (ST * WM * 128);        // + stage * WM * 128
+    const char *b_rows = lds + ST * A_STAGE + wn * (ST * WN * 128);
     __builtin_amdgcn_s_setprio(1);                      // the MFMA stream goes first on its SIMD
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -351,11 +361,15 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     // of fragment reads is issued one MFMA group (20 MFMAs, 320 cycles) before its first use, and a wave reaches the
     // barrier with its reads of stage t complete -- the invariant the loaders refill on.
     uint4 fa[2][TM], fb[2][TN];
-    auto rd = [&](auto buf_c, auto stage_c, auto h_c) {
-        constexpr int buf = decltype(buf_c)::value, stage = decltype(stage_c)::value, h = decltype(h_c)::value;
+    // stage: 0 .. ST - 1, a RUNTIME wave-uniform value (one v_add per group of reads): the loop below is not unrolled over the
+    // ring, and its body has ONE chain of MFMAs (the last step is peeled) -- with the MFMAs of a phase in both arms of an
+    // `if (more steps)` the accumulators were allocated twice (239 VGPRs for the 64 x 80 wave tile instead of 162; the
+    // 64 x 128 tile spilled)
+    auto rd = [&](auto buf_c, uint32_t stage, auto h_c) {
+        constexpr int buf = decltype(buf_c)::value, h = decltype(h_c)::value;
         if constexpr (DIAG == 1) return;
-        const char *As = a_rows + stage * STAGE + (h ? fbase1 : fbase0);
-        const char *Bs = b_rows + stage * STAGE + (h ? fbase1 : fbase0);
+        const char *As = a_rows + (stage * (uint32_t)(WM * 128) + (uint32_t)(h ? fbase1 : fbase0));
+        const char *Bs = b_rows + (stage * (uint32_t)(WN * 128) + (uint32_t)(h ? fbase1 : fbase0));
 #pragma unroll
         for (int b = 0; b < TN; ++b) fb[buf][b] = *reinterpret_cast<const uint4 *>(Bs + b * 2048);
 #pragma unroll
@@ -373,53 +387,49 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
     // Within a phase the fragment reads are interleaved into the MFMA stream, one ds_read_b128 behind each of the first
     // TM + TN MFMAs: a read issued in an MFMA's shadow costs no issue time, and none is needed before the next phase
     // (block scheduling: the reads-then-MFMAs order cost ~250 cycles of a 900-cycle step with the MFMA pipe idle).
     auto interleave = [&]() {
-        if constexpr (DIAG == 0 && INTERLEAVE) {
+        if constexpr ((DIAG == 0 || DIAG >= 3) && INTERLEAVE) {
 #pragma unroll
             for (int i = 0; i < TM + TN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);    // MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - MPR * (TM + TN), 0);
         }
     };
-    auto step = [&](auto stage_c, auto next_c, bool more) {
-        rd(I1{}, stage_c, I1{});                        // (t, h1) -> buffer 1
+    auto first_half = [&](uint32_t stage) {
+        rd(I1{}, stage, I1{});                          // (t, h1) -> buffer 1
         if constexpr (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
         mm(I0{});                                       // (t, h0)
         interleave();
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of stage t have returned
-            __builtin_amdgcn_s_barrier();               // barrier t + 1
-            asm volatile("" ::: "memory");
-            rd(I0{}, next_c, I0{});                     // (t + 1, h0) -> buffer 0
-            if constexpr (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
-            mm(I1{});                                   // (t, h1)
-            interleave();
-        } else {
-            mm(I1{});
-        }
+    };
+    auto second_half = [&](uint32_t next) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's reads of stage t have returned
+        __builtin_amdgcn_s_barrier();                   // barrier t + 1
+        asm volatile("" ::: "memory");
+        rd(I0{}, next, I0{});                           // (t + 1, h0) -> buffer 0
+        if constexpr (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+        mm(I1{});                                       // (t, h1)
+        interleave();
         __builtin_amdgcn_sched_barrier(0);
     };
     __builtin_amdgcn_s_barrier();                       // barrier 0
     asm volatile("" ::: "memory");
-    rd(I0{}, I0{}, I0{});
-    for (int kt = 0; kt < nk; kt += ST) {
-        step(I0{}, I1{}, kt + 1 < nk);
-        if (kt + 1 < nk) step(I1{}, I2{}, kt + 2 < nk);
-        if constexpr (ST == 3) {
-            if (kt + 2 < nk) step(I2{}, I0{}, kt + 3 < nk);
-        } else {
-            if (kt + 2 < nk) step(I2{}, I3{}, kt + 3 < nk);
-            if (kt + 3 < nk) step(I3{}, I0{}, kt + 4 < nk);
-        }
+    rd(I0{}, 0u, I0{});
+    uint32_t stage = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const uint32_t next = stage + 1 == (uint32_t)ST ? 0u : stage + 1;
+        first_half(stage);
+        second_half(next);
+        stage = next;
     }
+    first_half(stage);                                  // the last step: nothing left to read ahead
+    mm(I1{});
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // final barrier: every wave's last fragment read is behind it
@@ -947,6 +957,8 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
     do { \
         if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 1>), g, blk, 0, st, p); \
         else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 2>), g, blk, 0, st, p); \
+        else if (diag == 3) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 3>), g, blk, 0, st, p); \
+        else if (diag == 4) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 4>), g, blk, 0, st, p); \
         else hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_>), g, blk, 0, st, p); \
     } while (0)
 #define BNN_DENSE_PICK(TN_, NWM_, NWN_, ST_) \

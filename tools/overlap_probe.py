@@ -66,3 +66,18 @@ print("two gemm streams: %.2f us per pair (alone %.2f each)" % (tbb, tb))
 ga2 = graph_of(draw, N, sb)
 taa = run([(ga, sa), (ga2, sb)])
 print("two draw streams: %.2f us per pair (alone %.2f each)" % (taa, ta))
+
+# one graph with two parallel branches (fork / join inside the capture): does the graph executor run them concurrently?
+main = torch.cuda.Stream(dev)
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.stream(main):
+    with torch.cuda.graph(g2, stream=main):
+        sa.wait_stream(main)
+        with torch.cuda.stream(sa):
+            for _ in range(N):
+                draw()
+        for _ in range(N):
+            gemm()
+        main.wait_stream(sa)
+tg = run([(g2, main)])
+print("ONE graph, draw branch || gemm branch: %.2f us per pair" % tg)
