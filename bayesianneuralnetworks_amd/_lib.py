@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BNN_HIP_LIB: another build of the same C-ABI (A/B measurements); default = the in-tree library
 LIB_PATH = os.environ.get("BNN_HIP_LIB") or os.path.join(_HERE, "libbnn_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
 FLAG_RELU = 1
 FLAG_X_BF16 = 2
@@ -102,6 +102,9 @@ SIGNATURES = {
                                              _i64, _int, _rngp, _rngp, _int, _int, ctypes.POINTER(KlTensor), _int, _p, _p]),
     "bnn_draw_multi": (_int, [ctypes.POINTER(DrawTensor), _int, _int, ctypes.POINTER(KlTensor), _int, _p, _p]),
     "bnn_dense_forward": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p]),
+    "bnn_dense_forward_x3": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64,
+                                    _i64, _i64, _i64, _int, _int, _p]),
+    "bnn_split_bf16x3": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p]),
     "bnn_conv2d_dense_forward": (_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape), _int, _int, _p]),
     "bnn_conv2d_flipout_forward": (_int, [_p, _p, _i64, _p, _p, _p, ctypes.POINTER(Conv2dShape), _int, _p]),
     "bnn_linear_forward": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,

@@ -53,7 +53,7 @@ struct DrawTensorDev {
     void *out;
     int64_t out_sample_stride;  // elements
     int32_t rows, cols, ld;     // (rows, cols) posterior, output rows of ld >= cols elements (zeros beyond cols)
-    int32_t bf16;               // output dtype
+    int32_t bf16;               // output: 0 fp32, 1 bf16, 2 three bf16 planes h, m, l (plane stride = nsamples * out_sample_stride)
     int32_t kind;               // 0: draw mu + sigma eps; 1: mu as it is; 2: sigma = 1e-10 + softplus(rho) (Flipout's two operands)
     int32_t perm_taps;          // > 1: a conv weight (O, C, KH, KW) written tap-major: column c * taps + t -> t * (cols / taps) + c
     int32_t first_item;         // first work item (8-column group) of this tensor within the launch
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     const int64_t t_stride = L.t[ti].out_sample_stride;
     const int t_rows = L.t[ti].rows, t_cols = L.t[ti].cols, t_ld = L.t[ti].ld;
     const bool t_bf16 = L.t[ti].bf16 != 0;
+    const bool t_x3 = L.t[ti].bf16 == 2;
     const int t_taps = L.t[ti].perm_taps;
     const int t_kind = L.t[ti].kind;
     const RngDev rng = L.t[ti].rng;
@@ -106,12 +107,14 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     const int esz = t_bf16 ? 2 : 4;
     char *const dst0 = t_out + orow * esz;
     const int64_t sbytes = t_stride * esz;
+    const int64_t pbytes = sbytes * L.nsamples;     // (three-plane output)
     if (c0 >= t_cols) {
         // padding columns: zeros (the dense kernel's K tail multiplies them with clamped, finite activations)
         for (int s = 0; s < S; ++s) {
             if (s % (int)gridDim.y != (int)blockIdx.y) continue;
-            if (t_bf16) *reinterpret_cast<uint4 *>(dst0 + s * sbytes) = make_uint4(0u, 0u, 0u, 0u);
-            else
+            if (t_bf16) {
+                for (int pl = 0; pl < (t_x3 ? 3 : 1); ++pl) *reinterpret_cast<uint4 *>(dst0 + s * sbytes + pl * pbytes) = make_uint4(0u, 0u, 0u, 0u);
+            } else
                 for (int j = 0; j < 8; ++j)
                     if (c0 + j < t_ld) reinterpret_cast<float *>(dst0 + s * sbytes)[j] = 0.f;
         }
@@ -161,7 +164,14 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
         w[4] = fmaf(sg[4], zb.x, m[4]); w[5] = fmaf(sg[5], zb.y, m[5]);
         w[6] = fmaf(sg[6], zb.z, m[6]); w[7] = fmaf(sg[7], zb.w, m[7]);
         char *dst = dst0 + s * sbytes;
-        if (vec_store) {
+        if (vec_store && t_x3) {
+            uint4 h, m, l;
+            split_bf16x3(w[0], w[1], h.x, m.x, l.x); split_bf16x3(w[2], w[3], h.y, m.y, l.y);
+            split_bf16x3(w[4], w[5], h.z, m.z, l.z); split_bf16x3(w[6], w[7], h.w, m.w, l.w);
+            *reinterpret_cast<uint4 *>(dst) = h;
+            *reinterpret_cast<uint4 *>(dst + pbytes) = m;
+            *reinterpret_cast<uint4 *>(dst + 2 * pbytes) = l;
+        } else if (vec_store) {
             uint4 o;
             o.x = pack_bf16x2(w[0], w[1]); o.y = pack_bf16x2(w[2], w[3]);
             o.z = pack_bf16x2(w[4], w[5]); o.w = pack_bf16x2(w[6], w[7]);
@@ -180,7 +190,13 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
             for (int j = 0; j < 8; ++j) {
                 if (c0 + j >= t_ld) break;
                 const float v = j < nval ? w[j] : 0.f;
-                if (t_bf16) reinterpret_cast<uint16_t *>(dst)[j] = f2bf(v);
+                if (t_x3) {
+                    uint32_t h, m, l;
+                    split_bf16x3(v, 0.f, h, m, l);
+                    reinterpret_cast<uint16_t *>(dst)[j] = (uint16_t)h;
+                    reinterpret_cast<uint16_t *>(dst + pbytes)[j] = (uint16_t)m;
+                    reinterpret_cast<uint16_t *>(dst + 2 * pbytes)[j] = (uint16_t)l;
+                } else if (t_bf16) reinterpret_cast<uint16_t *>(dst)[j] = f2bf(v);
                 else reinterpret_cast<float *>(dst)[j] = v;
             }
         }
@@ -203,6 +219,10 @@ struct DenseParams {
     int32_t M, N, K, S;
     int32_t ntm, ntn;
     int32_t flags;              // BNN_FLAG_RELU, BNN_FLAG_Y_BF16
+    // fp32 parity mode (bnn_dense_forward_x3): every operand is THREE bf16 planes h, m, l (v = h + m + l to 2^-24 |v|), plane
+    // stride in elements; 0 = plain bf16 operands
+    int32_t x3;
+    int64_t a_plane_stride, w_plane_stride, y_plane_stride;
 };
 
 constexpr int kDenseNoXcdMap = 1 << 20;     // internal flag (BNN_DENSE_XCD=0): plain sample-major block order, for A/B runs
@@ -229,7 +249,7 @@ __device__ __forceinline__ void dma_piece(const void *base, uint32_t voff, uint3
 //   <4, 8, 4, 1, 3>: 256 x 128 tile for wide layers
 // DIAG (BNN_DENSE_DIAG): timing-only builds whose outputs are wrong: 1 = consumers skip reads and MFMAs, 2 = loaders skip the
 // DMA; correct builds for A/B runs of the read interleave: 3 = one MFMA per interleaved fragment read, 4 = two.
-template <int TM, int TN, int NWM, int NWN, int ST, bool YBF, bool RELU, int DIAG = 0>
+template <int TM, int TN, int NWM, int NWN, int ST, int YM, bool RELU, int DIAG = 0>
 __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
 {
     constexpr int NWV = 4;                              // consumer waves = loader waves
@@ -246,6 +266,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     constexpr int B_STAGE = BN * 128;
     constexpr int STAGE = A_STAGE + B_STAGE;
     // epilogue staging (after the final barrier): EPI_A 16-row blocks of the wave's output tile at a time in its quarter of the ring
+    constexpr bool YBF = YM != 0;                       // YM: 0 fp32, 1 bf16, 2 three bf16 planes (h, m, l) of the fp32 result
     constexpr int ESZ = YBF ? 2 : 4;
     constexpr int EPI_BYTES = ST * STAGE / NWV;
     constexpr int EPI_A = (EPI_BYTES / (16 * WN * ESZ)) < TM ? (EPI_BYTES / (16 * WN * ESZ)) : TM;
@@ -270,7 +291,10 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     const int m0 = mt * BM, n0 = panel * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = (p.K + 63) / 64;
+    // x3: the six largest partial products of (xh + xm + xl)(wh + wm + wl), smallest first, as six 64-k steps per k-block on
+    // plane pairs (l, h) (h, l) (m, m) (m, h) (h, m) (h, h) -- the consumers see a plain GEMM of depth 6 K (dropped terms
+    // <= 2^-25 |x w|: below one fp32 rounding; same products and order as bnn_linear.hip's kComputeBf16x3)
+    const int nk = (p.K + 63) / 64 * (p.x3 ? 6 : 1);
 
     if (wave >= NWV) {
         // =============================== loader ===============================
@@ -307,16 +331,24 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
             auto issue = [&](int kt) {
                 if constexpr (DIAG == 2) return;
                 const int stage = kt % ST;
-                const uint32_t colA0 = (uint32_t)(kt * 128 + 16 * schunk);
+                int kb = kt;
+                const char *ab = a_base, *wb = w_base;
+                if (p.x3) {
+                    kb = kt / 6;
+                    const int pr = kt - 6 * kb;
+                    ab += ((0x001102 >> (4 * pr)) & 3) * (p.a_plane_stride * 2);
+                    wb += ((0x010120 >> (4 * pr)) & 3) * (p.w_plane_stride * 2);
+                }
+                const uint32_t colA0 = (uint32_t)(kb * 128 + 16 * schunk);
                 const uint32_t colA = colA0 < a_colmax ? colA0 : a_colmax;   // k >= K: any finite chunk (the weights are 0 there)
-                const uint32_t colB = (uint32_t)(kt * 128);
+                const uint32_t colB = (uint32_t)(kb * 128);
                 const uint32_t sa = ring + (uint32_t)(stage * (WM * 128)), sb = ring + (uint32_t)(stage * (WN * 128));
 #pragma unroll
                 for (int j = 0; j < A_PIECES; ++j)
-                    dma_piece(a_base, a_off[j] + colA, sa + a_dst[j]);
+                    dma_piece(ab, a_off[j] + colA, sa + a_dst[j]);
 #pragma unroll
                 for (int j = 0; j < NBP; ++j)
-                    dma_piece(w_base, b_off[j] + colB, sb + b_dst[j]);
+                    dma_piece(wb, b_off[j] + colB, sb + b_dst[j]);
             };
 #pragma unroll
             for (int i = 0; i < ST - 1; ++i)
@@ -445,37 +477,51 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
         const int n = nw + b * 16 + fi;
         bv[b] = (bias && n < p.N) ? bias[n] : 0.f;
     }
+    // plane pl of the result: bf16(v), bf16(v - h), bf16(v - h - m) -- the split of split_bf16x3 (residuals exact in fp32)
+    auto plane_of = [&](float v, int pl) -> uint16_t {
+        const uint16_t h = f2bf(v);
+        if (pl == 0) return h;
+        const float r = v - __uint_as_float((uint32_t)h << 16);
+        const uint16_t m = f2bf(r);
+        if (pl == 1) return m;
+        return f2bf(r - __uint_as_float((uint32_t)m << 16));
+    };
+    constexpr int NP = YM == 2 ? 3 : 1;
     const bool wide = nw + WN <= p.N && mw + WM <= p.M && (p.ldy * ESZ) % 16 == 0 && (nw * ESZ) % 16 == 0 &&
-                      ((reinterpret_cast<uintptr_t>(p.Y) + ybase) & 15u) == 0;
+                      ((reinterpret_cast<uintptr_t>(p.Y) + ybase) & 15u) == 0 && (NP == 1 || (p.y_plane_stride * ESZ) % 16 == 0);
     if (wide) {
         char *T = lds + wave * EPI_BYTES;
         constexpr int pitch = WN * ESZ;
         constexpr int cpr = pitch / 16;
-        char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)mw * p.ldy + nw) * ESZ;
 #pragma unroll
-        for (int a0 = 0; a0 < TM; a0 += EPI_A) {
+        for (int pl = 0; pl < NP; ++pl) {
+            char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)pl * p.y_plane_stride + (int64_t)mw * p.ldy + nw) * ESZ;
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+            for (int a0 = 0; a0 < TM; a0 += EPI_A) {
 #pragma unroll
-                for (int a = a0; a < a0 + EPI_A && a < TM; ++a)
+                for (int b = 0; b < TN; ++b)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[a][b][r] + bv[b];
-                        if (RELU) v = fmaxf(v, 0.f);
-                        char *q = T + ((a - a0) * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * ESZ;
-                        if (YBF) *reinterpret_cast<uint16_t *>(q) = f2bf(v);
-                        else *reinterpret_cast<float *>(q) = v;
-                    }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's ds_writes before its ds_reads
-            __builtin_amdgcn_wave_barrier();
-            const int nrows = (TM - a0 < EPI_A ? TM - a0 : EPI_A) * 16;
-            for (int c = lane; c < nrows * cpr; c += 64) {
-                const int row = c / cpr, cc = c - row * cpr;
-                *reinterpret_cast<uint4 *>(Y8 + (int64_t)(a0 * 16 + row) * p.ldy * ESZ + cc * 16) =
-                    *reinterpret_cast<const uint4 *>(T + row * pitch + cc * 16);
+                    for (int a = a0; a < a0 + EPI_A && a < TM; ++a)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[a][b][r] + bv[b];
+                            if (RELU) v = fmaxf(v, 0.f);
+                            char *q = T + ((a - a0) * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * ESZ;
+                            if (YM == 2) *reinterpret_cast<uint16_t *>(q) = plane_of(v, pl);
+                            else if (YM == 1) *reinterpret_cast<uint16_t *>(q) = f2bf(v);
+                            else *reinterpret_cast<float *>(q) = v;
+                        }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's ds_writes before its ds_reads
+                __builtin_amdgcn_wave_barrier();
+                const int nrows = (TM - a0 < EPI_A ? TM - a0 : EPI_A) * 16;
+                for (int c = lane; c < nrows * cpr; c += 64) {
+                    const int row = c / cpr, cc = c - row * cpr;
+                    *reinterpret_cast<uint4 *>(Y8 + (int64_t)(a0 * 16 + row) * p.ldy * ESZ + cc * 16) =
+                        *reinterpret_cast<const uint4 *>(T + row * pitch + cc * 16);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // ... and its ds_reads before the next pass's ds_writes
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // ... and its ds_reads before the next pass's ds_writes
-            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
@@ -493,7 +539,10 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
                 if (m >= p.M) continue;
                 float v = acc[a][b][r] + bv[b];
                 if (RELU) v = fmaxf(v, 0.f);
-                if (YBF) Yh[(int64_t)m * p.ldy + n] = f2bf(v);
+                if (YM == 2) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) Yh[(int64_t)pl * p.y_plane_stride + (int64_t)m * p.ldy + n] = plane_of(v, pl);
+                } else if (YM == 1) Yh[(int64_t)m * p.ldy + n] = f2bf(v);
                 else Yf[(int64_t)m * p.ldy + n] = v;
             }
     }
@@ -844,6 +893,108 @@ static inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) 
 
 using namespace bnn;
 
+// fp32 -> three bf16 planes (h, m, l), 8 columns per thread
+__global__ __launch_bounds__(256) void k_split_bf16x3(const float *__restrict__ x, int gpr, int64_t ldx, uint16_t *__restrict__ out,
+                                                     int64_t ld_out, int64_t plane_stride, int items)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= items) return;
+    const int row = i / gpr, c0 = (i - row * gpr) * 8;
+    const float4 a = *reinterpret_cast<const float4 *>(x + (int64_t)row * ldx + c0);
+    const float4 b = *reinterpret_cast<const float4 *>(x + (int64_t)row * ldx + c0 + 4);
+    uint4 h, m, l;
+    split_bf16x3(a.x, a.y, h.x, m.x, l.x);
+    split_bf16x3(a.z, a.w, h.y, m.y, l.y);
+    split_bf16x3(b.x, b.y, h.z, m.z, l.z);
+    split_bf16x3(b.z, b.w, h.w, m.w, l.w);
+    uint16_t *o = out + (int64_t)row * ld_out + c0;
+    *reinterpret_cast<uint4 *>(o) = h;
+    *reinterpret_cast<uint4 *>(o + plane_stride) = m;
+    *reinterpret_cast<uint4 *>(o + 2 * plane_stride) = l;
+}
+
+static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,
+                        const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
+                        const float *b, int64_t b_sample_stride,
+                        void *y, int64_t y_plane_stride, int64_t y_sample_stride, int64_t ldy,
+                        int64_t M, int64_t N, int64_t K, int nsamples, int flags, bool x3, void *stream)
+{
+    if (M == 0 && N >= 1 && K >= 1 && nsamples >= 1) return BNN_OK;
+    if (!x || !w || !y) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldy < N) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    if (flags & ~(BNN_FLAG_RELU | BNN_FLAG_Y_BF16)) { set_error("%s: unknown flags", who); return BNN_E_UNSUPPORTED; }
+    const int64_t kp = (K + 63) / 64 * 64;
+    if (K % 8 != 0 || ldx % 8 != 0 || x_sample_stride % 8 != 0 || ldw % 8 != 0 || w_sample_stride % 8 != 0 || ldw < kp || !al16(x) || !al16(w)) {
+        set_error("%s: needs K %% 8 == 0, 16-B aligned bf16 rows, and weight rows zero-padded to ldw >= roundup(K, 64)", who);
+        return BNN_E_UNSUPPORTED;
+    }
+    if (M * ldx * 2 >= ((int64_t)1 << 32) || N * ldw * 2 >= ((int64_t)1 << 32)) { set_error("%s: one sample's operand exceeds 4 GiB", who); return BNN_E_RANGE; }
+    const bool ybf = (flags & BNN_FLAG_Y_BF16) != 0;
+    if (reinterpret_cast<uintptr_t>(y) & (ybf ? 1u : 3u)) { set_error("%s: misaligned output", who); return BNN_E_ALIGN; }
+    DenseParams p{};
+    p.A = reinterpret_cast<const uint16_t *>(x); p.a_sample_stride = x_sample_stride; p.lda = ldx;
+    p.W = reinterpret_cast<const uint16_t *>(w); p.w_sample_stride = w_sample_stride; p.ldw = ldw;
+    p.bias = b; p.bias_sample_stride = b_sample_stride;
+    p.Y = y; p.y_sample_stride = y_sample_stride; p.ldy = ldy;
+    p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.flags = flags;
+    if (x3) {
+        if (x_plane_stride % 8 != 0 || w_plane_stride % 8 != 0 || (ybf && y_plane_stride % 8 != 0) || x_plane_stride < M * ldx || w_plane_stride < N * ldw) {
+            set_error("%s: bad plane stride", who);
+            return BNN_E_SHAPE;
+        }
+        if (N <= 16) { set_error("%s: N <= 16 is not supported on three-plane operands (use bnn_linear_forward)", who); return BNN_E_UNSUPPORTED; }
+        p.x3 = 1;
+        p.a_plane_stride = x_plane_stride; p.w_plane_stride = w_plane_stride; p.y_plane_stride = y_plane_stride;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 16 && K <= 4 * kHeadMaxSteps * 32) {
+        p.ntm = (int32_t)((M + 15) / 16);
+        p.ntn = 1;
+        hipLaunchKernelGGL(k_head_bf16, dim3((unsigned)((int64_t)p.ntm * nsamples)), dim3(256), 0, st, p);
+        return check_launch(who);
+    }
+    static const bool no_xcd = [] { const char *e = getenv("BNN_DENSE_XCD"); return e && e[0] == '0'; }();
+    if (no_xcd) p.flags |= kDenseNoXcdMap;
+    // tile: the BASELINE-shaped layers (N % 80 == 0: 1200 = 7.5 x 160) take 128 x 160 with a 4-stage ring -- 36 KiB per
+    // 64-k step instead of 256 x 80's 42 for the same MFMAs, 4 x 8 x 8 = 256 workgroups; wide layers 256 x 128.
+    // BNN_DENSE_TILE = 0 (256 x 80), 1 (128 x 160), 2 (256 x 128) forces one for A/B runs.
+    static const int force_tile = [] { const char *e = getenv("BNN_DENSE_TILE"); return e ? atoi(e) : -1; }();
+    int tile = (N % 80 == 0 || N < 128) ? 1 : 2;
+    if (N <= 80) tile = 0;
+    if (force_tile >= 0 && force_tile <= 2) tile = force_tile;
+    const int bm = tile == 1 ? 128 : 256;
+    const int bn = tile == 0 ? 80 : tile == 1 ? 160 : 128;
+    p.ntm = (int32_t)((M + bm - 1) / bm);
+    p.ntn = (int32_t)((N + bn - 1) / bn);
+    const int64_t grid = (int64_t)p.ntm * p.ntn * nsamples;
+    if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
+    static const int diag = [] { const char *e = getenv("BNN_DENSE_DIAG"); return e ? atoi(e) : 0; }();
+    const bool relu = (flags & BNN_FLAG_RELU) != 0;
+    const dim3 g((unsigned)grid), blk(512);
+#define BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, RELU_) \
+    do { \
+        if (x3 && ybf) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 2, RELU_>), g, blk, 0, st, p); \
+        else if (!ybf) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 0, RELU_>), g, blk, 0, st, p); \
+        else if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 1>), g, blk, 0, st, p); \
+        else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 2>), g, blk, 0, st, p); \
+        else if (diag == 3) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 3>), g, blk, 0, st, p); \
+        else if (diag == 4) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 4>), g, blk, 0, st, p); \
+        else hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_>), g, blk, 0, st, p); \
+    } while (0)
+#define BNN_DENSE_PICK(TN_, NWM_, NWN_, ST_) \
+    do { \
+        if (relu) BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, true); else BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, false); \
+    } while (0)
+    if (tile == 0) BNN_DENSE_PICK(5, 4, 1, 3);
+    else if (tile == 1) BNN_DENSE_PICK(5, 2, 2, 4);
+    else BNN_DENSE_PICK(8, 4, 1, 3);
+#undef BNN_DENSE_PICK
+#undef BNN_DENSE_LAUNCH
+    return check_launch(who);
+}
+
+
 extern "C" {
 
 int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
@@ -861,20 +1012,21 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         const bnn_draw_tensor_t &t = tensors[i];
         if (!t.mu || !t.rho || !t.out) { set_error("%s: tensor %d: NULL pointer", who, i); return BNN_E_NULL; }
         if (t.rows < 1 || t.cols < 1 || t.ld < t.cols || t.rows > 0x7FFFFFFF || t.ld > 0x7FFFFFFF) { set_error("%s: tensor %d: bad extent", who, i); return BNN_E_SHAPE; }
-        if (t.out_dtype != BNN_F32 && t.out_dtype != BNN_BF16) { set_error("%s: tensor %d: unknown dtype", who, i); return BNN_E_DTYPE; }
+        if (t.out_dtype != BNN_F32 && t.out_dtype != BNN_BF16 && t.out_dtype != BNN_BF16X3) { set_error("%s: tensor %d: unknown dtype", who, i); return BNN_E_DTYPE; }
         // a Philox block is 4 consecutive elements of the flat tensor and a work item 8 columns of one row
         if (t.rows > 1 && t.cols % 4 != 0) { set_error("%s: tensor %d: cols %% 4 != 0 (use bnn_sample_affine_philox)", who, i); return BNN_E_UNSUPPORTED; }
         if (t.ld % 8 != 0 && t.rows > 1) { set_error("%s: tensor %d: ld %% 8 != 0", who, i); return BNN_E_UNSUPPORTED; }
-        if (t.out_dtype == BNN_BF16 && (!al16(t.out) || t.out_sample_stride % 8 != 0 || t.ld % 8 != 0)) { set_error("%s: tensor %d: bf16 output needs 16-B aligned rows", who, i); return BNN_E_ALIGN; }
+        if (t.out_dtype != BNN_F32 && (!al16(t.out) || t.out_sample_stride % 8 != 0 || t.ld % 8 != 0)) { set_error("%s: tensor %d: bf16 output needs 16-B aligned rows", who, i); return BNN_E_ALIGN; }
         if ((reinterpret_cast<uintptr_t>(t.mu) | reinterpret_cast<uintptr_t>(t.rho) | reinterpret_cast<uintptr_t>(t.out)) & 3u) { set_error("%s: tensor %d: misaligned pointer", who, i); return BNN_E_ALIGN; }
         const int rc = t.kind == 0 ? check_rng(&t.rng, nsamples) : BNN_OK;
         if (rc) { set_error("%s: tensor %d: bad rng", who, i); return rc; }
         DrawTensorDev &d = L.t[i];
         d.mu = t.mu; d.rho = t.rho; d.out = t.out; d.out_sample_stride = t.out_sample_stride;
-        d.rows = (int32_t)t.rows; d.cols = (int32_t)t.cols; d.ld = (int32_t)t.ld; d.bf16 = t.out_dtype == BNN_BF16;
+        d.rows = (int32_t)t.rows; d.cols = (int32_t)t.cols; d.ld = (int32_t)t.ld; d.bf16 = t.out_dtype == BNN_BF16 ? 1 : t.out_dtype == BNN_BF16X3 ? 2 : 0;
         d.perm_taps = t.taps > 1 ? t.taps : 1;
         d.kind = t.kind;
         if (t.kind < 0 || t.kind > 2) { set_error("%s: tensor %d: kind must be 0 (draw), 1 (mean) or 2 (stddev)", who, i); return BNN_E_RANGE; }
+        if (t.out_dtype == BNN_BF16X3 && t.kind != 0) { set_error("%s: tensor %d: three-plane output is for draws (kind 0)", who, i); return BNN_E_UNSUPPORTED; }
         if (t.taps > 1 && (t.cols % t.taps != 0 || t.out_dtype != BNN_BF16)) { set_error("%s: tensor %d: taps must divide cols (bf16 output)", who, i); return BNN_E_SHAPE; }
         d.first_item = (int32_t)items;
         d.rng = make_rng(&t.rng);
@@ -908,69 +1060,34 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
                       void *y, int64_t y_sample_stride, int64_t ldy,
                       int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream)
 {
-    const char *who = "bnn_dense_forward";
-    if (M == 0 && N >= 1 && K >= 1 && nsamples >= 1) return BNN_OK;
-    if (!x || !w || !y) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
-    if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldy < N) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
-    if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
-    if (flags & ~(BNN_FLAG_RELU | BNN_FLAG_Y_BF16)) { set_error("%s: unknown flags", who); return BNN_E_UNSUPPORTED; }
-    const int64_t kp = (K + 63) / 64 * 64;
-    if (K % 8 != 0 || ldx % 8 != 0 || x_sample_stride % 8 != 0 || ldw % 8 != 0 || w_sample_stride % 8 != 0 || ldw < kp || !al16(x) || !al16(w)) {
-        set_error("%s: needs K %% 8 == 0, 16-B aligned bf16 rows, and weight rows zero-padded to ldw >= roundup(K, 64)", who);
+    return dense_launch("bnn_dense_forward", x, 0, x_sample_stride, ldx, w, 0, w_sample_stride, ldw, b, b_sample_stride,
+                        y, 0, y_sample_stride, ldy, M, N, K, nsamples, flags, false, stream);
+}
+
+int bnn_dense_forward_x3(const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,
+                         const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
+                         const float *b, int64_t b_sample_stride,
+                         void *y, int64_t y_plane_stride, int64_t y_sample_stride, int64_t ldy,
+                         int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream)
+{
+    return dense_launch("bnn_dense_forward_x3", x, x_plane_stride, x_sample_stride, ldx, w, w_plane_stride, w_sample_stride, ldw,
+                        b, b_sample_stride, y, y_plane_stride, y_sample_stride, ldy, M, N, K, nsamples, flags, true, stream);
+}
+
+int bnn_split_bf16x3(const float *x, int64_t rows, int64_t cols, int64_t ldx, void *out, int64_t ld_out, int64_t plane_stride, void *stream)
+{
+    const char *who = "bnn_split_bf16x3";
+    if (rows == 0 && cols >= 1) return BNN_OK;
+    if (!x || !out) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (rows < 0 || cols < 1 || ldx < cols || ld_out < cols) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (cols % 8 != 0 || ldx % 4 != 0 || ld_out % 8 != 0 || plane_stride % 8 != 0 || !al16(x) || !al16(out)) {
+        set_error("%s: needs cols %% 8 == 0 and 16-B aligned rows on both sides", who);
         return BNN_E_UNSUPPORTED;
     }
-    if (M * ldx * 2 >= ((int64_t)1 << 32) || N * ldw * 2 >= ((int64_t)1 << 32)) { set_error("%s: one sample's operand exceeds 4 GiB", who); return BNN_E_RANGE; }
-    const bool ybf = (flags & BNN_FLAG_Y_BF16) != 0;
-    if (reinterpret_cast<uintptr_t>(y) & (ybf ? 1u : 3u)) { set_error("%s: misaligned output", who); return BNN_E_ALIGN; }
-    DenseParams p{};
-    p.A = reinterpret_cast<const uint16_t *>(x); p.a_sample_stride = x_sample_stride; p.lda = ldx;
-    p.W = reinterpret_cast<const uint16_t *>(w); p.w_sample_stride = w_sample_stride; p.ldw = ldw;
-    p.bias = b; p.bias_sample_stride = b_sample_stride;
-    p.Y = y; p.y_sample_stride = y_sample_stride; p.ldy = ldy;
-    p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.flags = flags;
-    hipStream_t st = (hipStream_t)stream;
-    if (N <= 16 && K <= 4 * kHeadMaxSteps * 32) {
-        p.ntm = (int32_t)((M + 15) / 16);
-        p.ntn = 1;
-        hipLaunchKernelGGL(k_head_bf16, dim3((unsigned)((int64_t)p.ntm * nsamples)), dim3(256), 0, st, p);
-        return check_launch(who);
-    }
-    static const bool no_xcd = [] { const char *e = getenv("BNN_DENSE_XCD"); return e && e[0] == '0'; }();
-    if (no_xcd) p.flags |= kDenseNoXcdMap;
-    // tile: the BASELINE-shaped layers (N % 80 == 0: 1200 = 7.5 x 160) take 128 x 160 with a 4-stage ring -- 36 KiB per
-    // 64-k step instead of 256 x 80's 42 for the same MFMAs, 4 x 8 x 8 = 256 workgroups; wide layers 256 x 128.
-    // BNN_DENSE_TILE = 0 (256 x 80), 1 (128 x 160), 2 (256 x 128) forces one for A/B runs.
-    static const int force_tile = [] { const char *e = getenv("BNN_DENSE_TILE"); return e ? atoi(e) : -1; }();
-    int tile = (N % 80 == 0 || N < 128) ? 1 : 2;
-    if (N <= 80) tile = 0;
-    if (force_tile >= 0 && force_tile <= 2) tile = force_tile;
-    const int bm = tile == 1 ? 128 : 256;
-    const int bn = tile == 0 ? 80 : tile == 1 ? 160 : 128;
-    p.ntm = (int32_t)((M + bm - 1) / bm);
-    p.ntn = (int32_t)((N + bn - 1) / bn);
-    const int64_t grid = (int64_t)p.ntm * p.ntn * nsamples;
-    if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
-    static const int diag = [] { const char *e = getenv("BNN_DENSE_DIAG"); return e ? atoi(e) : 0; }();
-    const bool relu = (flags & BNN_FLAG_RELU) != 0;
-    const dim3 g((unsigned)grid), blk(512);
-#define BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, YBF_, RELU_) \
-    do { \
-        if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 1>), g, blk, 0, st, p); \
-        else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 2>), g, blk, 0, st, p); \
-        else if (diag == 3) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 3>), g, blk, 0, st, p); \
-        else if (diag == 4) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_, 4>), g, blk, 0, st, p); \
-        else hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, YBF_, RELU_>), g, blk, 0, st, p); \
-    } while (0)
-#define BNN_DENSE_PICK(TN_, NWM_, NWN_, ST_) \
-    do { \
-        if (ybf) { if (relu) BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, true, true); else BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, true, false); } \
-        else { if (relu) BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, false, true); else BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, false, false); } \
-    } while (0)
-    if (tile == 0) BNN_DENSE_PICK(5, 4, 1, 3);
-    else if (tile == 1) BNN_DENSE_PICK(5, 2, 2, 4);
-    else BNN_DENSE_PICK(8, 4, 1, 3);
-#undef BNN_DENSE_PICK
-#undef BNN_DENSE_LAUNCH
+    const int64_t items = rows * (cols / 8);
+    if (items > 0x7FFFFFFF) { set_error("%s: too many elements", who); return BNN_E_RANGE; }
+    hipLaunchKernelGGL(k_split_bf16x3, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, (int)(cols / 8), ldx, reinterpret_cast<uint16_t *>(out), ld_out, plane_stride, (int)items);
     return check_launch(who);
 }
 

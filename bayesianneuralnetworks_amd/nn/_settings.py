@@ -39,7 +39,10 @@ def fuse_activations(module, bf16_activations=False):
     * bf16_activations=True additionally lets a fused NormalLinear whose output feeds the next
       NormalLinear (through the Identity) emit that hidden activation in bf16 -- used only while
       the compute mode is 'bf16', where the consumer would round it to bf16 anyway, so results
-      are identical to fp32 hidden activations; it halves the consumer's activation stream.
+      are identical to fp32 hidden activations; it halves the consumer's activation stream.  In the
+      'f32' mode the same pairs (wide consumer, inference) pass the activation as the three bf16
+      planes of its fp32 value (ops.X3Activation, exact to 2^-24), the operand format of the dense
+      kernel's parity mode.
 
     Returns the number of fused pairs."""
     import torch
@@ -63,4 +66,7 @@ def fuse_activations(module, bf16_activations=False):
                             j += 1
                         if j < len(mods) and type(mods[j]) is NormalLinear and mods[j].in_channels % 8 == 0:
                             la.out_dtype = torch.bfloat16
+                            # ... and in the fp32 parity mode, when the consumer is a wide layer that runs on the dense kernel
+                            # too, as the three bf16 planes that kernel reads (ops.X3Activation): same values, no split pass
+                            la.out_x3 = mods[j].weight.mean.shape[0] > 16
     return fused

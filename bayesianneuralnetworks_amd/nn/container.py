@@ -107,29 +107,43 @@ class BayesianNetworkModule(Module):
         from .dense import NormalLinear
         if not ops.DRAW_ONCE_BF16:
             return []
-        todo = []
+        todo, todo3 = [], []
+        infer = not torch.is_grad_enabled()
         for m in self.modules():
-            if type(m) is NormalLinear and m.weight.mean.is_cuda and (m.compute or _settings.get_compute()) == "bf16" \
-                    and ops.dense_eligible(m.weight.mean):
+            if type(m) is not NormalLinear or not m.weight.mean.is_cuda or not ops.dense_eligible(m.weight.mean):
+                continue
+            if (m.compute or _settings.get_compute()) == "bf16":
                 todo.append(m)
-        if not todo:
+            elif ops.DENSE_X3_F32 and (infer or not m.weight.mean.requires_grad) and m.weight.mean.shape[0] > 16 and ctx.base_batch >= 64:
+                todo3.append(m)         # fp32 parity mode, inference: the same plan with three-plane draws (ops.linear_sampled_x3)
+        if not todo and not todo3:
             return []
-        specs = []
-        for m in todo:
-            m.sample(ctx.samples, ctx.sample0)
-            kw, kb = m._keys(ctx.samples)
-            specs.append((m.weight.mean.detach(), m.weight.scale.detach(),
-                          m.bias.mean.detach() if m.bias is not None else None,
-                          m.bias.scale.detach() if m.bias is not None else None, kw, kb))
+
+        def specs_of(mods):
+            specs = []
+            for m in mods:
+                m.sample(ctx.samples, ctx.sample0)
+                kw, kb = m._keys(ctx.samples)
+                specs.append((m.weight.mean.detach(), m.weight.scale.detach(),
+                              m.bias.mean.detach() if m.bias is not None else None,
+                              m.bias.scale.detach() if m.bias is not None else None, kw, kb))
+            return specs
+
         kl = ops._tls.kl_carry
-        if ops.DRAW_SIDE_STREAM and len(specs) > 1:
-            # the first layer's weights on the main stream; the rest (and the KL's first pass) on a side stream, where the
-            # VALU-bound draw runs beside the first layer's draw and DMA / MFMA-bound contraction
-            dev = specs[0][0].device
-            pre = ops.draw_layers(specs[:1], ctx.samples)
-            pre += ops.draw_layers(specs[1:], ctx.samples, kl=kl, stream=ops.side_stream(dev))
-        else:
-            pre = ops.draw_layers(specs, ctx.samples, kl=kl)
+        pre = []
+        if todo:
+            specs = specs_of(todo)
+            if ops.DRAW_SIDE_STREAM and len(specs) > 1:
+                # the first layer's weights on the main stream; the rest (and the KL's first pass) on a side stream, where the
+                # VALU-bound draw runs beside the first layer's draw and DMA / MFMA-bound contraction
+                dev = specs[0][0].device
+                pre = ops.draw_layers(specs[:1], ctx.samples)
+                pre += ops.draw_layers(specs[1:], ctx.samples, kl=kl, stream=ops.side_stream(dev))
+            else:
+                pre = ops.draw_layers(specs, ctx.samples, kl=kl)
+        if todo3:
+            pre += ops.draw_layers(specs_of(todo3), ctx.samples, kl=kl if (kl is not None and not kl.launched) else None, x3=True)
+        todo = todo + todo3
         if kl is not None and kl.launched:
             ops._tls.kl_carry = None
         for m, p_ in zip(todo, pre):

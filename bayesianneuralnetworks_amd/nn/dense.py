@@ -94,6 +94,18 @@ class _NormalSampling:
             self.sample(S, s0)
         return S, s0, shared, per
 
+    def _x3_call(self, x, rows):
+        """fp32 parity mode on the dense kernel?  Inference only (the backward kernels take the fused path's saved tensors),
+        a 2-D fp32 input or an X3Activation, a wide layer."""
+        if not ops.DENSE_X3_F32:
+            return False
+        if torch.is_grad_enabled() and (self.weight.mean.requires_grad or (torch.is_tensor(x) and x.requires_grad)):
+            return False
+        if torch.is_tensor(x) and (x.dim() != 2 or x.dtype != torch.float32):
+            return False
+        x2 = x if isinstance(x, ops.X3Activation) else x
+        return ops.x3_eligible(x2, self.weight.mean, rows)
+
     def _keys(self, S):
         kw = self.weight.draw_key
         kb = self.bias.draw_key if self.bias is not None else None
@@ -134,18 +146,34 @@ class NormalLinear(_NormalSampling, BayesianLinear):
             if sample and pd[0] is _mc.current():
                 predrawn, sample = pd[1], False
         S, _, shared, per = self._mc_plan(x, sample)
+        keys = self._keys(S)
+        mode = self._compute_mode()
+        if keys is not None and mode != "bf16" and self._x3_call(x, per):
+            # fp32 parity mode, inference: the draw-once dense path on three bf16 planes per operand (ops.linear_sampled_x3);
+            # a hidden layer that feeds another dense layer hands its result on in that format (out_x3, nn.fuse_activations)
+            K = x.shape[-1]
+            x2 = x if isinstance(x, ops.X3Activation) else (x.reshape(-1, K) if shared else x.reshape(S, -1, K))
+            y = ops.linear_sampled_x3(x2, shared, per, self.weight.mean.detach(), self.weight.scale.detach(),
+                                      self.bias.mean.detach() if self.bias is not None else None,
+                                      self.bias.scale.detach() if self.bias is not None else None,
+                                      keys[0], keys[1], relu=self.activation == 'relu',
+                                      planes_out=bool(getattr(self, "out_x3", False)),
+                                      predrawn=predrawn if (predrawn is not None and predrawn.w.dim() == 4) else None)
+            if isinstance(y, ops.X3Activation):
+                return y
+            return y.reshape(S * per, y.shape[-1])
+        if isinstance(x, ops.X3Activation):
+            x = x.float()
         lead = x.shape[1:-1]
         K = x.shape[-1]
         x2 = x.reshape(-1, K) if shared else x.reshape(S, -1, K)
-        keys = self._keys(S)
-        mode = self._compute_mode()
         if keys is not None:
             odt = torch.bfloat16 if (self.out_dtype == torch.bfloat16 and mode == "bf16") else torch.float32
             y = ops.linear_sampled(x2, self.weight.mean, self.weight.scale,
                                    self.bias.mean if self.bias is not None else None,
                                    self.bias.scale if self.bias is not None else None,
                                    keys[0], keys[1], shared, mode, relu=self.activation == 'relu',
-                                   out_dtype=odt, predrawn=predrawn if mode == "bf16" else None)
+                                   out_dtype=odt, predrawn=predrawn if (mode == "bf16" and predrawn is not None and predrawn.w.dim() == 3) else None)
         else:
             # weights were set explicitly (parity mode / user-assigned .sampled)
             w, b = self.sampled

@@ -142,8 +142,9 @@ def dense_eligible(mu_w):
 
 
 class Predrawn:
-    """The drawn weights of one layer for one forward: w (S, N, Kp) bf16 zero-padded to Kp = roundup(K, 64),
-    b (S, N) fp32 or None, and the DrawKeys they were drawn with.  `ready`: the side stream the draw was launched on
+    """The drawn weights of one layer for one forward: w (S, N, Kp) bf16 zero-padded to Kp = roundup(K, 64) -- or, drawn
+    for the fp32 parity mode, (3, S, N, Kp): the three bf16 planes of the fp32 draw -- b (S, N) fp32 or None, and the
+    DrawKeys they were drawn with.  `ready`: the side stream the draw was launched on
     (the consumer's stream waits for it before the contraction), or None."""
     __slots__ = ("w", "b", "key_w", "key_b", "ready")
 
@@ -173,11 +174,12 @@ def side_stream(device):
     return st
 
 
-def draw_layers(layers, nsamples, kl=None, stream=None):
+def draw_layers(layers, nsamples, kl=None, stream=None, x3=False):
     """ONE launch (bnn_draw_multi) draws the weights and biases of every (mu_w, rho_w, mu_b, rho_b, key_w, key_b) in
     `layers` for `nsamples` MC samples -> list of Predrawn.  kl (a KlDeferred from kl_normal_begin(carry=True)): the
     launch also carries that KL's first pass.  At most 4 layers (8 tensors) per launch; more are split.
-    stream: launch on that side stream (forked from the current one here; consumers join through Predrawn.wait())."""
+    stream: launch on that side stream (forked from the current one here; consumers join through Predrawn.wait()).
+    x3: weights as three bf16 planes of the fp32 draw (BNN_BF16X3; the fp32 parity mode's dense path)."""
     out = []
     lib = _lib.load()
     dev = layers[0][0].device
@@ -199,10 +201,10 @@ def draw_layers(layers, nsamples, kl=None, stream=None):
             require_cuda_f32(rho_w, "weight.scale")
             N, K = mu_w.shape
             kp = _pad64(K)
-            w = torch.empty((nsamples, N, kp), dtype=torch.bfloat16, device=dev)
+            w = torch.empty(((3, nsamples, N, kp) if x3 else (nsamples, N, kp)), dtype=torch.bfloat16, device=dev)
             t = arr[n]
             t.mu, t.rho, t.rows, t.cols = mu_w.data_ptr(), rho_w.data_ptr(), N, K
-            t.out, t.ld, t.out_sample_stride, t.out_dtype = w.data_ptr(), kp, N * kp, _lib.BF16
+            t.out, t.ld, t.out_sample_stride, t.out_dtype = w.data_ptr(), kp, N * kp, (_lib.BF16X3 if x3 else _lib.BF16)
             t.taps = taps
             t.rng = _rng_struct(key_w, dev)
             n += 1
@@ -256,6 +258,102 @@ def _dense_raw(x2, x_sample_stride, M, pre, K, relu, out_dtype, ldx=None, pad_ro
                                          ptr(pre.b), N if pre.b is not None else 0, ptr(ybuf), M * ldy, ldy, M, N, K, S, flags,
                                          stream_ptr(x2.device)), "bnn_dense_forward")
     return ybuf if ldy == N else ybuf[:, :, :N]
+
+
+class X3Activation:
+    """A hidden activation of the fp32 parity mode as it travels between two dense layers: the fp32 values as three bf16
+    planes (3, S, M, ld) (h, m, l: v = h + m + l to 2^-24 |v|), `cols` valid columns.  Not a tensor: only NormalLinear
+    consumes it (nn.fuse_activations arranges that); .float() gives the fp32 tensor back."""
+    __slots__ = ("planes", "cols")
+
+    def __init__(self, planes, cols):
+        self.planes, self.cols = planes, cols
+
+    @property
+    def shape(self):
+        return torch.Size((self.planes.shape[1] * self.planes.shape[2], self.cols))
+
+    @property
+    def is_cuda(self):
+        return self.planes.is_cuda
+
+    @property
+    def device(self):
+        return self.planes.device
+
+    def dim(self):
+        return 2
+
+    def float(self):
+        p = self.planes[..., :self.cols].float()
+        return (p[0] + p[1] + p[2]).reshape(-1, self.cols)
+
+
+def split_x3(x2):
+    """fp32 (M, K) -> (3, 1, M, roundup(K, 64)) bf16 planes (bnn_split_bf16x3)."""
+    require_cuda_f32(x2, "x")
+    M, K = x2.shape
+    ld = _pad64(K)
+    out = torch.empty((3, 1, M, ld), dtype=torch.bfloat16, device=x2.device)
+    check(_lib.load().bnn_split_bf16x3(ptr(x2), M, K, x2.stride(0) if M > 1 else K, ptr(out), ld, M * ld, stream_ptr(x2.device)),
+          "bnn_split_bf16x3")
+    return out
+
+
+def x3_eligible(x2, mu_w, M):
+    """fp32 parity mode on the dense kernel: a wide layer (N > 16) with whole 8-column groups on an fp32 (M, K) input or an
+    X3Activation."""
+    N, K = mu_w.shape
+    if not (dense_eligible(mu_w) and N > 16 and M >= 64):
+        return False
+    if isinstance(x2, X3Activation):
+        return True
+    return x2.dtype == torch.float32 and x2.dim() == 2 and x2.stride(-1) == 1 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
+
+
+def _dense_raw_x3(xp, shared, M, pre, K, relu, planes_out):
+    """y = act(x . w_s^T + b_s) in the fp32 parity mode on three-plane operands (bnn_dense_forward_x3).
+    xp: (3, S or 1, M, ldx) planes; pre.w (3, S, N, kp).  planes_out: the result as an X3Activation (for the next dense
+    layer) instead of an fp32 (S, M, N) tensor."""
+    _, S, N, kp = pre.w.shape
+    ldx = xp.shape[3]
+    xs = 0 if shared else M * ldx
+    if planes_out:
+        ldy = _pad64(N)
+        y = torch.empty((3, S, M, ldy), dtype=torch.bfloat16, device=xp.device)
+        yps = S * M * ldy
+    else:
+        ldy = N
+        y = torch.empty((S, M, N), dtype=torch.float32, device=xp.device)
+        yps = 0
+    flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_Y_BF16 if planes_out else 0)
+    check(_lib.load().bnn_dense_forward_x3(ptr(xp), xp.shape[1] * M * ldx, xs, ldx, ptr(pre.w), S * N * kp, N * kp, kp,
+                                            ptr(pre.b), N if pre.b is not None else 0, ptr(y), yps, M * ldy, ldy, M, N, K, S, flags,
+                                            stream_ptr(xp.device)), "bnn_dense_forward_x3")
+    return X3Activation(y, N) if planes_out else y
+
+
+def linear_sampled_x3(x2, shared, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, relu=False, planes_out=False, predrawn=None):
+    """Inference call of NormalLinear in the fp32 parity mode (no autograd: the caller checked that no gradient is wanted):
+    draw once as three bf16 planes (or `predrawn` by the network's draw plan), contract on the dense kernel."""
+    S = key_w.nsamples
+    N, K = mu_w.shape
+    pre = predrawn
+    if pre is None:
+        pre = draw_layers([(mu_w, rho_w, mu_b, rho_b, key_w, key_b)], S, kl=_tls.kl_carry, x3=True)[0]
+        if _tls.kl_carry is not None and _tls.kl_carry.launched:
+            _tls.kl_carry = None
+    pre.wait()
+    if isinstance(x2, X3Activation):
+        xp = x2.planes
+        if xp.shape[1] not in (1, S) or xp.shape[2] != M or x2.cols != K:
+            raise BnnHipError("linear: three-plane activation of shape %s does not fit (S = %d, M = %d, K = %d)" % (tuple(xp.shape), S, M, K))
+        shared = xp.shape[1] == 1
+    else:
+        xp = split_x3(x2.reshape(-1, K))            # (3, 1, rows, ld); rows = M (shared) or S * M
+        if not shared:
+            xp = xp.view(3, S, M, xp.shape[3])
+    return _dense_raw_x3(xp, shared, M, pre, K, relu, planes_out)
 
 
 # --------------------------------------------------------------------------- K2 linear
@@ -330,6 +428,7 @@ _tls = _ThreadState()
 DRAW_ONCE_MIN_ROWS = 2048
 # bf16 compute mode: draw once + dense GEMM at every batch size (False: the round-1 fused kernel, kept for A/B runs)
 DRAW_ONCE_BF16 = True
+DENSE_X3_F32 = os.environ.get("BNN_DENSE_X3", "1") != "0"    # fp32 parity mode of wide inference layers on the dense kernel
 # BNN_DRAW_SIDE=1: a network draw plan launches the layers after the first on a side stream, beside the first layer draw + contraction
 # (measured on the BASELINE step: SLOWER, 0.0832 vs 0.0749 ms -- the cross-queue dependency costs more than the overlap hides; off)
 DRAW_SIDE_STREAM = os.environ.get("BNN_DRAW_SIDE", "0") == "1"

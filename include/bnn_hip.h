@@ -51,7 +51,9 @@ enum {
     BNN_E_DEVICE = -7     /* a kernel reported an internal error through the device error word (bnn_check_device) */
 };
 
-enum { BNN_F32 = 0, BNN_BF16 = 1 };
+enum { BNN_F32 = 0, BNN_BF16 = 1,
+       BNN_BF16X3 = 2 /* an fp32 value as THREE bf16 planes h, m, l: h = bf16(v), m = bf16(v - h), l = bf16(v - h - m), v = h + m + l
+                       * to 2^-24 |v| -- the operand format of the fp32 parity mode's dense contraction (bnn_dense_forward_x3) */ };
 
 /* Compute mode of the contraction kernels. */
 enum {
@@ -220,7 +222,8 @@ typedef struct bnn_draw_tensor {
     void *out;                  /* draw s at out + s * out_sample_stride elements: `rows` rows of `ld` elements */
     int64_t ld;                 /* >= cols (% 8 == 0 when rows > 1); columns cols .. ld - 1 are written as ZEROS */
     int64_t out_sample_stride;  /* elements */
-    int out_dtype;              /* BNN_F32 or BNN_BF16 */
+    int out_dtype;              /* BNN_F32, BNN_BF16, or BNN_BF16X3: three planes, plane p of draw s at
+                                 * out + (p * nsamples + s) * out_sample_stride (kind 0, taps <= 1) */
     int kind;                   /* 0: draw mu + sigma(rho) eps (rng used); 1: mu itself; 2: sigma(rho) itself (no eps: Flipout's
                                  * two operands, nsamples = 1) */
     int taps;                   /* 0 / 1: rows are written as they are.  KH * KW of a conv weight (O, C, KH, KW) viewed as
@@ -243,6 +246,22 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
                       const float *b, int64_t b_sample_stride,
                       void *y, int64_t y_sample_stride, int64_t ldy,
                       int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream);
+/* The same layer in the fp32 PARITY mode (1e-5 against the reference) on the same kernel: x and w are BNN_BF16X3 operands
+ * (plane p at + p * plane_stride elements; x from bnn_split_bf16x3 or a previous layer's BNN_FLAG_Y_BF16 output, w from
+ * bnn_draw_multi with out_dtype BNN_BF16X3) and the contraction runs the six largest partial products of
+ * (xh + xm + xl)(wh + wm + wl) on the bf16 MFMA with fp32 accumulation -- dropped terms <= 2^-25 |x w|, below one fp32
+ * rounding; what BNN_COMPUTE_F32 does inside bnn_linear_forward_sampled.  y: fp32, or (BNN_FLAG_Y_BF16) three bf16
+ * planes of the fp32 result, y_plane_stride apart, for the next layer.  N > 16.
+ * replaces  F.linear(x, *self.sampled)  pytorch_bayesian/nn/dense.py:60 */
+int bnn_dense_forward_x3(const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,
+                         const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
+                         const float *b, int64_t b_sample_stride,
+                         void *y, int64_t y_plane_stride, int64_t y_sample_stride, int64_t ldy,
+                         int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream);
+/* fp32 (rows x cols, row pitch ldx) -> BNN_BF16X3 planes (row pitch ld_out, planes plane_stride elements apart): the
+ * input of the first bnn_dense_forward_x3 of a network.  cols % 8 == 0, 16-B aligned rows. */
+int bnn_split_bf16x3(const float *x, int64_t rows, int64_t cols, int64_t ldx, void *out, int64_t ld_out, int64_t plane_stride,
+                     void *stream);
 
 /* Same contraction with the weights given (F.linear(x, w, b), dense.py:60):
  * w[s] = w + s * w_sample_stride, b[s] = b + s * b_sample_stride (b may be NULL). */

@@ -1,0 +1,198 @@
+"""GPU parity of the fp32 PARITY mode on the dense kernel (csrc/bnn_dense.hip: bnn_split_bf16x3, bnn_draw_multi with
+BNN_BF16X3 output, bnn_dense_forward_x3): every operand as three bf16 planes, six partial products per k-block on the
+bf16 MFMA.  Tolerance: 1e-5 of the output scale against the CPU oracle in double on the same Philox draws -- the fp32
+mode's bar (north_star), same as the fused kernel's."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import allclose_scaled
+import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    assert torch.cuda.is_available()
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd import _lib, ops
+    from oracle import oracle as orc
+    return dict(bnn=bnn, lib=_lib.load(), _lib=_lib, ops=ops, orc=orc, dev=torch.device("cuda:0"))
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+def _post(shape, seed, dev):
+    gen = torch.Generator().manual_seed(seed)
+    return [t.to(dev) for t in seeded.posterior(gen, shape, True)]
+
+
+def _planes_sum(p):
+    return p[0].double() + p[1].double() + p[2].double()
+
+
+@pytest.mark.parametrize("M,K", [(512, 784), (3, 8), (65, 1200)])
+def test_split_planes_are_the_exact_three_term_expansion(env, M, K):
+    ops, dev = env["ops"], env["dev"]
+    x = torch.randn(M, K, device=dev) * torch.logspace(-6, 6, K, device=dev)
+    p = ops.split_x3(x)
+    assert p.shape == (3, 1, M, (K + 63) // 64 * 64) and p.dtype == torch.bfloat16
+    h = x.bfloat16()
+    assert torch.equal(p[0, 0, :, :K], h)                                       # plane 0 IS the bf16 rounding
+    r = x - h.float()
+    assert torch.equal(p[1, 0, :, :K], r.bfloat16())
+    assert torch.equal(p[2, 0, :, :K], (r - r.bfloat16().float()).bfloat16())
+    err = (_planes_sum(p[:, 0, :, :K]) - x.double()).abs()
+    assert (err <= x.abs().double() * 2.0 ** -24 + 1e-300).all()
+
+
+@pytest.mark.parametrize("shape,S", [((1200, 784), 8), ((80, 264), 2), ((40, 16), 1)])
+def test_three_plane_draw_sums_to_the_fp32_draw(env, shape, S):
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    ops, dev = env["ops"], env["dev"]
+    mw, rw, mb, rb = _post(shape, 5, dev)
+    kw, kb = DrawKey(99, 11, 2, S, 7), DrawKey(99, 12, 2, S, 7)
+    n0 = env["lib"].bnn_launch_count()
+    pre = ops.draw_layers([(mw, rw, mb, rb, kw, kb)], S, x3=True)[0]
+    assert env["lib"].bnn_launch_count() == n0 + 1
+    Nn, K = shape
+    kp = (K + 63) // 64 * 64
+    assert pre.w.shape == (3, S, Nn, kp)
+    w32 = ops._sample_affine_philox_raw(mw, rw, kw)                             # the fp32 draw of the same key (K1)
+    assert torch.equal(pre.w[0, :, :, :K], w32.bfloat16())
+    err = (_planes_sum(pre.w[:, :, :, :K]) - w32.double()).abs()
+    assert (err <= w32.abs().double() * 2.0 ** -24).all()
+    assert (pre.w[:, :, :, K:] == 0).all()
+    assert torch.equal(pre.b, ops._sample_affine_philox_raw(mb, rb, kb))
+
+
+X3_SHAPES = [  # S, M, N, K, shared, relu, planes_out
+    (8, 512, 1200, 784, True, True, True),
+    (8, 512, 1200, 1200, False, True, False),
+    (2, 100, 200, 72, True, False, False),
+    (1, 64, 48, 8, True, True, True),
+    (3, 130, 170, 200, False, False, True),
+    (1, 300, 4096, 256, True, False, False),
+]
+
+
+@pytest.mark.parametrize("S,M,Nn,K,shared,relu,planes_out", X3_SHAPES)
+def test_dense_x3_vs_double(env, S, M, Nn, K, shared, relu, planes_out):
+    ops, dev = env["ops"], env["dev"]
+    g = torch.Generator().manual_seed(S * 1000 + M)
+    x = torch.randn((M, K) if shared else (S, M, K), generator=g).to(dev)
+    w = (torch.randn(S, Nn, K, generator=g) * 0.1).to(dev)
+    b = torch.randn(S, Nn, generator=g).to(dev)
+    kp = (K + 63) // 64 * 64
+    wp = torch.zeros(3, S, Nn, kp, dtype=torch.bfloat16, device=dev)
+    wp[:, :, :, :K] = ops.split_x3(w.reshape(S * Nn, K))[:, 0, :, :K].reshape(3, S, Nn, K)
+    pre = ops.Predrawn(wp, b, None, None)
+    xp = ops.split_x3(x.reshape(-1, K))
+    if not shared:
+        xp = xp.view(3, S, M, xp.shape[3])
+    y = ops._dense_raw_x3(xp, shared, M, pre, K, relu, planes_out)
+    if planes_out:
+        assert isinstance(y, ops.X3Activation) and y.planes.shape[:3] == (3, S, M)
+        got = y.float().reshape(S, M, Nn)
+    else:
+        got = y
+    xd = x.double() if not shared else x.double().unsqueeze(0).expand(S, M, K)
+    want = torch.einsum("smk,snk->smn", xd, w.double()) + b.double().unsqueeze(1)
+    if relu:
+        want = want.clamp_min(0)
+    allclose_scaled(N(got), want.cpu().numpy(), 1e-5)
+    if planes_out:
+        # the planes are the split of the kernel's own fp32 result: re-splitting their sum reproduces them
+        v = y.float().reshape(S, M, Nn)
+        h = v.bfloat16()
+        r = v - h.float()
+        assert torch.equal(y.planes[0, ..., :Nn], h) and torch.equal(y.planes[1, ..., :Nn], r.bfloat16())
+        assert torch.equal(y.planes[2, ..., :Nn], (r - r.bfloat16().float()).bfloat16())
+
+
+def test_dense_x3_argument_errors(env):
+    lib, _lib, dev = env["lib"], env["_lib"], env["dev"]
+    a = torch.zeros(3, 1, 64, 64, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(3, 1, 32, 64, dtype=torch.bfloat16, device=dev)
+    y = torch.zeros(1, 64, 32, device=dev)
+    sp = _lib.stream_ptr(dev)
+    ok = lib.bnn_dense_forward_x3(_lib.ptr(a), 64 * 64, 0, 64, _lib.ptr(w), 32 * 64, 32 * 64, 64, None, 0, _lib.ptr(y), 0, 64 * 32, 32, 64, 32, 64, 1, 0, sp)
+    assert ok == 0
+    # N <= 16: not on three-plane operands
+    assert lib.bnn_dense_forward_x3(_lib.ptr(a), 64 * 64, 0, 64, _lib.ptr(w), 32 * 64, 32 * 64, 64, None, 0, _lib.ptr(y), 0, 64 * 16, 16, 64, 16, 64, 1, 0, sp) == _lib.E_UNSUPPORTED
+    # a plane stride smaller than one plane
+    assert lib.bnn_dense_forward_x3(_lib.ptr(a), 8, 0, 64, _lib.ptr(w), 32 * 64, 32 * 64, 64, None, 0, _lib.ptr(y), 0, 64 * 32, 32, 64, 32, 64, 1, 0, sp) != 0
+    x = torch.zeros(4, 12, device=dev)
+    o = torch.zeros(3, 4, 64, dtype=torch.bfloat16, device=dev)
+    assert lib.bnn_split_bf16x3(_lib.ptr(x), 4, 12, 12, _lib.ptr(o), 64, 4 * 64, sp) == _lib.E_UNSUPPORTED   # cols % 8
+
+
+@pytest.mark.parametrize("dims,B,S", [((784, 1200, 1200, 10), 512, 8), ((96, 200, 120, 10), 70, 4)])
+def test_fp32_mode_network_on_dense_path_equals_fused_kernels_and_oracle(env, dims, B, S):
+    """The same MLP forward in the fp32 parity mode on both implementations -- three-plane dense path (draw plan + X3
+    activations between the hidden layers) and the fused in-kernel-draw kernels -- same DrawKeys: both within 1e-5 of the
+    oracle in double, and of each other."""
+    bnn, ops, orc, dev = env["bnn"], env["ops"], env["orc"], env["dev"]
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule, fuse_activations
+    gen = torch.Generator().manual_seed(3)
+    post = [seeded.posterior(gen, (dims[i + 1], dims[i]), True) for i in range(len(dims) - 1)]
+
+    class MLP(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(dims[0], dims[-1], S)
+            mods = []
+            for j, (mw, rw, mb, rb) in enumerate(post):
+                L = NormalLinear(mw.shape[1], mw.shape[0])
+                with torch.no_grad():
+                    L.weight.mean.copy_(mw); L.weight.scale.copy_(rw); L.bias.mean.copy_(mb); L.bias.scale.copy_(rb)
+                mods.append(L)
+                if j < len(post) - 1:
+                    mods.append(torch.nn.ReLU())
+            self.layers = torch.nn.Sequential(*mods)
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    net = MLP().to(dev)
+    net.mc_batched = True
+    fuse_activations(net, bf16_activations=True)
+    x = torch.randn(B, dims[0], generator=gen).to(dev)
+    old_mode = bnn.get_compute() if hasattr(bnn, "get_compute") else "f32"
+    bnn.set_compute("f32")
+    saved = ops.DENSE_X3_F32
+    try:
+        outs = {}
+        for x3 in (True, False):
+            ops.DENSE_X3_F32 = x3
+            bnn.manual_seed(11)
+            n0 = env["lib"].bnn_launch_count()
+            with torch.no_grad():
+                outs[x3] = net.forward_stacked(x, S)
+            launches = env["lib"].bnn_launch_count() - n0
+            if x3:
+                # draw (all wide layers) + split + one dense launch per wide layer + the fused head
+                assert launches == 2 + (len(dims) - 2) + 1, launches
+            keys = [(L.weight.draw_key, L.bias.draw_key) for L in net.layers if hasattr(L, "weight")]
+            outs[(x3, "keys")] = keys
+    finally:
+        ops.DENSE_X3_F32 = saved
+        bnn.set_compute(old_mode)
+    allclose_scaled(N(outs[True]), N(outs[False]), 2e-5)
+    # oracle on the recorded keys (sample by sample, double accumulation)
+    keys = outs[(True, "keys")]
+    xs = N(x)[:48]
+    for s in range(S):
+        h = xs.astype(np.float64)
+        for j, (mw, rw, mb, rb) in enumerate(post):
+            kw, kb = keys[j]
+            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, tuple(mw.shape))
+            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, tuple(mb.shape))
+            w = orc.sample_affine(mw.numpy(), rw.numpy(), ew).astype(np.float64)
+            b = orc.sample_affine(mb.numpy(), rb.numpy(), eb).astype(np.float64)
+            h = h @ w.T + b
+            if j < len(post) - 1:
+                h = np.maximum(h, 0)
+        allclose_scaled(N(outs[True][s, :48]), h, 1e-5)
