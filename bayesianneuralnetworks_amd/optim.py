@@ -1,7 +1,14 @@
 """Optimizer step of the reference's training loop on the device (examples/MNIST/train.py:41,65):
 torch.optim.Adam semantics (amsgrad = False, maximize = False, L2 weight_decay), every parameter
 tensor of the model updated by ONE HIP launch (csrc/bnn_train.hip) -- graph-capturable, the step
-counter lives on the device."""
+counter lives on the device.
+
+Deviations from torch.optim.Adam (pinned by tests/test_hip_parity.py::test_fused_adam_matches_torch_adam at
+rtol 1e-5 over the first steps, where they are largest): ONE step counter per parameter group (torch: one per
+parameter -- the same value whenever every parameter of the group has a gradient, as in the reference's loop)
+and the bias corrections 1 - beta^t evaluated in fp32 on the device (torch: Python doubles), about 6e-5 relative
+on the very first updates.  The state_dict therefore holds `step` in the group, not per parameter: it is not
+interchangeable with torch.optim.Adam's."""
 import ctypes
 
 import torch
