@@ -572,24 +572,33 @@ __global__ __launch_bounds__(256) void k_head_bf16(const DenseParams p)
     const uint16_t *wrow = p.W + (int64_t)s * p.w_sample_stride + (int64_t)n * p.ldw;
     uint4 af[kHeadMaxSteps], bfr[kHeadMaxSteps];
     const int kmax = p.K - 8;
-#pragma unroll
-    for (int i = 0; i < kHeadMaxSteps; ++i) {
-        const int kt = k0 + i;
-        int ka = kt * 32 + 8 * fq;
-        const int kb = ka;
-        ka = ka < kmax ? ka : kmax;                 // k >= K: clamped (finite) activations x zero-padded weights
-        if (kt < k1) {
-            af[i] = *reinterpret_cast<const uint4 *>(arow + ka);
-            bfr[i] = *reinterpret_cast<const uint4 *>(wrow + kb);
-        } else {
-            af[i] = make_uint4(0u, 0u, 0u, 0u);
-            bfr[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    // three-plane operands (fp32 parity mode): the same pass six times, on plane pairs (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+    const int npass = p.x3 ? 6 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const uint16_t *ar = arow, *wr = wrow;
+        if (p.x3) {
+            ar += ((0x001102 >> (4 * pass)) & 3) * p.a_plane_stride;
+            wr += ((0x010120 >> (4 * pass)) & 3) * p.w_plane_stride;
+        }
 #pragma unroll
-    for (int i = 0; i < kHeadMaxSteps; ++i)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bfr[i]), acc, 0, 0, 0);
+        for (int i = 0; i < kHeadMaxSteps; ++i) {
+            const int kt = k0 + i;
+            int ka = kt * 32 + 8 * fq;
+            const int kb = ka;
+            ka = ka < kmax ? ka : kmax;                 // k >= K: clamped (finite) activations x zero-padded weights
+            if (kt < k1) {
+                af[i] = *reinterpret_cast<const uint4 *>(ar + ka);
+                bfr[i] = *reinterpret_cast<const uint4 *>(wr + kb);
+            } else {
+                af[i] = make_uint4(0u, 0u, 0u, 0u);
+                bfr[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kHeadMaxSteps; ++i)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bfr[i]), acc, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][fq * 4 + r][fi] = acc[r];
     __syncthreads();
@@ -943,7 +952,7 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
             set_error("%s: bad plane stride", who);
             return BNN_E_SHAPE;
         }
-        if (N <= 16) { set_error("%s: N <= 16 is not supported on three-plane operands (use bnn_linear_forward)", who); return BNN_E_UNSUPPORTED; }
+        if (N <= 16 && (K > 4 * kHeadMaxSteps * 32 || ybf)) { set_error("%s: a narrow layer (N <= 16) on three-plane operands needs K <= %d and fp32 outputs", who, 4 * kHeadMaxSteps * 32); return BNN_E_UNSUPPORTED; }
         p.x3 = 1;
         p.a_plane_stride = x_plane_stride; p.w_plane_stride = w_plane_stride; p.y_plane_stride = y_plane_stride;
     }
@@ -1047,10 +1056,11 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
     int split = 1;
     while (split < nsamples && (int64_t)L.draw_blocks * split < 1024) split *= 2;
     if (split > nsamples) split = nsamples;
+    // BNN_DRAW_SPLIT forces the split for A/B runs (the BASELINE launch: 26.1 / 24.7 / 27.6 / 37.2 us with 1 / 2 / 4 / 8; in the
+    // pipelined bench 156 / 153 / 143 k MC-samples/s with 1 / 2 / 4)
     static const int force_split = [] { const char *e = getenv("BNN_DRAW_SPLIT"); return e ? atoi(e) : 0; }();
     if (force_split >= 1 && force_split <= nsamples) split = force_split;
-    static const int dyn_lds = [] { const char *e = getenv("BNN_DRAW_LDS"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL(k_draw_multi<1>, dim3((unsigned)grid, (unsigned)split), dim3(256), (size_t)dyn_lds, (hipStream_t)stream, L);
+    hipLaunchKernelGGL(k_draw_multi<1>, dim3((unsigned)grid, (unsigned)split), dim3(256), 0, (hipStream_t)stream, L);
     return check_launch(who);
 }
 

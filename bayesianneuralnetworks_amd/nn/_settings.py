@@ -66,7 +66,7 @@ def fuse_activations(module, bf16_activations=False):
                             j += 1
                         if j < len(mods) and type(mods[j]) is NormalLinear and mods[j].in_channels % 8 == 0:
                             la.out_dtype = torch.bfloat16
-                            # ... and in the fp32 parity mode, when the consumer is a wide layer that runs on the dense kernel
-                            # too, as the three bf16 planes that kernel reads (ops.X3Activation): same values, no split pass
-                            la.out_x3 = mods[j].weight.mean.shape[0] > 16
+                            # ... and in the fp32 parity mode, when the consumer runs on the dense kernels too, as the three
+                            # bf16 planes they read (ops.X3Activation): same values, no split pass
+                            la.out_x3 = mods[j].weight.mean.shape[0] > 16 or mods[j].in_channels <= 2048
     return fused

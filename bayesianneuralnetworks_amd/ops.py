@@ -301,10 +301,10 @@ def split_x3(x2):
 
 
 def x3_eligible(x2, mu_w, M):
-    """fp32 parity mode on the dense kernel: a wide layer (N > 16) with whole 8-column groups on an fp32 (M, K) input or an
-    X3Activation."""
+    """fp32 parity mode on the dense kernels: whole 8-column groups, a batch worth the draw-once path, an fp32 (M, K) input
+    or an X3Activation; a narrow layer (N <= 16: the K-split head kernel) up to K = 2048."""
     N, K = mu_w.shape
-    if not (dense_eligible(mu_w) and N > 16 and M >= 64):
+    if not (dense_eligible(mu_w) and M >= 64 and (N > 16 or K <= 2048)):
         return False
     if isinstance(x2, X3Activation):
         return True

@@ -251,7 +251,8 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
  * bnn_draw_multi with out_dtype BNN_BF16X3) and the contraction runs the six largest partial products of
  * (xh + xm + xl)(wh + wm + wl) on the bf16 MFMA with fp32 accumulation -- dropped terms <= 2^-25 |x w|, below one fp32
  * rounding; what BNN_COMPUTE_F32 does inside bnn_linear_forward_sampled.  y: fp32, or (BNN_FLAG_Y_BF16) three bf16
- * planes of the fp32 result, y_plane_stride apart, for the next layer.  N > 16.
+ * planes of the fp32 result, y_plane_stride apart, for the next layer.  N <= 16 (a classifier head: K <= 2048, fp32
+ * outputs) runs the K-split kernel, the six plane pairs as six passes.
  * replaces  F.linear(x, *self.sampled)  pytorch_bayesian/nn/dense.py:60 */
 int bnn_dense_forward_x3(const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,
                          const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,

@@ -76,6 +76,8 @@ X3_SHAPES = [  # S, M, N, K, shared, relu, planes_out
     (1, 64, 48, 8, True, True, True),
     (3, 130, 170, 200, False, False, True),
     (1, 300, 4096, 256, True, False, False),
+    (8, 512, 10, 1200, False, False, False),       # the classifier head: K-split kernel, six passes
+    (2, 70, 16, 2048, True, True, False),
 ]
 
 
@@ -121,8 +123,9 @@ def test_dense_x3_argument_errors(env):
     sp = _lib.stream_ptr(dev)
     ok = lib.bnn_dense_forward_x3(_lib.ptr(a), 64 * 64, 0, 64, _lib.ptr(w), 32 * 64, 32 * 64, 64, None, 0, _lib.ptr(y), 0, 64 * 32, 32, 64, 32, 64, 1, 0, sp)
     assert ok == 0
-    # N <= 16: not on three-plane operands
-    assert lib.bnn_dense_forward_x3(_lib.ptr(a), 64 * 64, 0, 64, _lib.ptr(w), 32 * 64, 32 * 64, 64, None, 0, _lib.ptr(y), 0, 64 * 16, 16, 64, 16, 64, 1, 0, sp) == _lib.E_UNSUPPORTED
+    # N <= 16: fp32 outputs only
+    assert lib.bnn_dense_forward_x3(_lib.ptr(a), 64 * 64, 0, 64, _lib.ptr(w), 32 * 64, 32 * 64, 64, None, 0, _lib.ptr(y), 64 * 16, 64 * 16, 16, 64, 16, 64, 1,
+                                    _lib.FLAG_Y_BF16, sp) == _lib.E_UNSUPPORTED
     # a plane stride smaller than one plane
     assert lib.bnn_dense_forward_x3(_lib.ptr(a), 8, 0, 64, _lib.ptr(w), 32 * 64, 32 * 64, 64, None, 0, _lib.ptr(y), 0, 64 * 32, 32, 64, 32, 64, 1, 0, sp) != 0
     x = torch.zeros(4, 12, device=dev)
@@ -173,8 +176,8 @@ def test_fp32_mode_network_on_dense_path_equals_fused_kernels_and_oracle(env, di
                 outs[x3] = net.forward_stacked(x, S)
             launches = env["lib"].bnn_launch_count() - n0
             if x3:
-                # draw (all wide layers) + split + one dense launch per wide layer + the fused head
-                assert launches == 2 + (len(dims) - 2) + 1, launches
+                # draw (every layer) + split of the input + one dense launch per layer
+                assert launches == 2 + (len(dims) - 1), launches
             keys = [(L.weight.draw_key, L.bias.draw_key) for L in net.layers if hasattr(L, "weight")]
             outs[(x3, "keys")] = keys
     finally:
