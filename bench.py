@@ -508,7 +508,7 @@ def kernel_roofline(net, x, mode, dev):
         us = _graph_time(lambda: ops._dense_raw(hv, BATCH * ld, BATCH, pre, DIMS[1], True, torch.bfloat16, ldx=ld, pad_rows=True), dev)
         us_draw = _graph_time(lambda: ops.draw_layers([spec], SAMPLES), dev)
         ach = flops / us / 1e6
-        out.update({"kernel": "k_dense_bf16<4,5>: layer 2, 512x1200x1200 x8 samples on drawn weights (%s)" % tag,
+        out.update({"kernel": "k_dense_bf16<4,5,2,2,4> (128x160 tile, 4-stage ring): layer 2, 512x1200x1200 x8 samples on drawn weights (%s)" % tag,
                     "achieved": round(ach, 2), "frac": round(ach / PEAK[mode], 4), "avg_launch_us": round(us, 2),
                     "algorithmic_bytes_per_launch": SAMPLES * (BATCH * DIMS[1] * 2 + DIMS[2] * DIMS[1] * 2 + BATCH * DIMS[2] * 2),
                     "layer_end_to_end": {"draw_us": round(us_draw, 2), "total_us": round(us + us_draw, 2),
@@ -517,15 +517,21 @@ def kernel_roofline(net, x, mode, dev):
                                          "note": "layer 2 alone = its own draw launch (8 x 1.44 M weights) + the contraction; in the step the "
                                                  "draw of all three layers is ONE launch (roofline_draw)"}})
         return out
-    layer.compute = mode
-    with torch.no_grad(), _mc.McContext(SAMPLES, BATCH, 0):
-        us = _graph_time(lambda: layer(h), dev)
-    layer.compute = None
+    # fp32 parity mode: the same dense kernel on three bf16 planes per operand, six plane-pair k-steps per k-block
+    # (bnn_dense_forward_x3); its weights come from the step's one draw launch (three planes), its input planes from layer
+    # 1's epilogue.  FLOPs counted once (the fp32 contraction's), peak = the fp32 MFMA rate the mode replaces.
+    kw, kb = DrawKey(1, 1, 0, SAMPLES, 0), DrawKey(1, 2, 0, SAMPLES, 0)
+    spec = (layer.weight.mean.detach(), layer.weight.scale.detach(), layer.bias.mean.detach(), layer.bias.scale.detach(), kw, kb)
+    pre = ops.draw_layers([spec], SAMPLES, x3=True)[0]
+    xp = ops.split_x3(h).view(3, SAMPLES, BATCH, -1)
+    us = _graph_time(lambda: ops._dense_raw_x3(xp, False, BATCH, pre, DIMS[1], True, False), dev)
+    us_draw = _graph_time(lambda: ops.draw_layers([spec], SAMPLES, x3=True), dev)
     ach = flops / us / 1e6
-    out.update({"kernel": "k_linear_sym<bf16x3>: sampled layer 2, 512x1200x1200 x8 samples, fused draw (%s)" % tag,
+    out.update({"kernel": "k_dense_bf16<4,5,2,2,4> on three-plane operands (bf16x3): layer 2, 512x1200x1200 x8 samples (%s)" % tag,
                 "achieved": round(ach, 2), "frac": round(ach / PEAK[mode], 4), "avg_launch_us": round(us, 2),
-                "algorithmic_param_bytes_per_launch": pbytes,
-                "algorithmic_bytes_per_launch": pbytes + SAMPLES * BATCH * (DIMS[1] * 4 + DIMS[2] * 4)})
+                "algorithmic_bytes_per_launch": SAMPLES * (BATCH * DIMS[1] * 6 + DIMS[2] * DIMS[1] * 6 + BATCH * DIMS[2] * 4),
+                "mfma_flop_per_launch": 6 * flops,
+                "layer_end_to_end": {"draw_us": round(us_draw, 2), "total_us": round(us + us_draw, 2)}})
     return out
 
 
@@ -842,7 +848,7 @@ def main(argv=None):
                 line["scaling"] = "weak"
         if "f32" in results and args.dtype != "f32":
             line["f32"] = {"value": round(results["f32"][0], 1), "ms_per_step": round(results["f32"][1], 4),
-                           "note": "same step in the 1e-5 parity mode (fp32 operands; wide layers as bf16x3 splits on the bf16 MFMA)"}
+                           "note": "same step in the 1e-5 parity mode: every operand as three bf16 planes on the dense kernel (six plane-pair k-steps per k-block), fp32 accumulate"}
         line["roofline"] = kernel_roofline(net, x, args.dtype, dev)
         if args.dtype == "bf16":
             line["roofline_draw"] = draw_roofline(net, dev)
