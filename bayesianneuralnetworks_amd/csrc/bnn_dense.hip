@@ -902,6 +902,7 @@ static inline bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) 
 
 using namespace bnn;
 
+namespace bnn {
 // fp32 -> three bf16 planes (h, m, l), 8 columns per thread
 __global__ __launch_bounds__(256) void k_split_bf16x3(const float *__restrict__ x, int gpr, int64_t ldx, uint16_t *__restrict__ out,
                                                      int64_t ld_out, int64_t plane_stride, int items)
@@ -921,6 +922,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float *__restrict__ 
     *reinterpret_cast<uint4 *>(o + plane_stride) = m;
     *reinterpret_cast<uint4 *>(o + 2 * plane_stride) = l;
 }
+}  // namespace bnn
 
 static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,
                         const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
