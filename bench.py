@@ -786,11 +786,16 @@ def main(argv=None):
             single = results[mode]
             pipe = PipelinedSteps(net, x_in, args.inflight, rank, world, **skw)
             pdt = time_steps(pipe, steps, args.warmup, world, dev)
-            results[mode] = (total * steps / pdt, pdt / steps * 1e3, steps)
-            pipeline = {"steps_in_flight": args.inflight, "single_stream_value": round(single[0], 1),
+            piped = (total * steps / pdt, pdt / steps * 1e3, steps)
+            # both are K timed steps between barriers (max over ranks, so every rank decides alike): the line reports the
+            # higher throughput and says which arrangement it was
+            results[mode] = piped if piped[0] >= single[0] else single
+            pipeline = {"steps_in_flight": args.inflight, "reported": "pipelined" if piped[0] >= single[0] else "single_stream",
+                        "pipelined_value": round(piped[0], 1), "pipelined_ms_per_step": round(piped[1], 4),
+                        "single_stream_value": round(single[0], 1),
                         "single_stream_ms_per_step": round(single[1], 4),
-                        "note": "value / ms_per_step are the pipelined THROUGHPUT (K complete steps / wall time); one "
-                                "step's latency is single_stream_ms_per_step"}
+                        "note": "pipelined = `steps_in_flight` complete steps in flight on as many streams: THROUGHPUT (K complete "
+                                "steps / wall time); one step's latency is single_stream_ms_per_step"}
             if world == 1:
                 # what the steps' LAST replays -- executed while the others were in flight -- left behind, against the oracle
                 pchks = [oracle_check(st, post, x_cpu, mode, replay=False) for st in pipe.steps]

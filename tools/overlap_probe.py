@@ -81,3 +81,33 @@ with torch.cuda.stream(main):
         main.wait_stream(sa)
 tg = run([(g2, main)])
 print("ONE graph, draw branch || gemm branch: %.2f us per pair" % tg)
+
+# stream priorities: GEMM chain on a high-priority stream, draws on a low-priority one -- does the dispatcher prefer the GEMM?
+lo_, hi_ = torch.cuda.Stream(dev, priority=0), torch.cuda.Stream(dev, priority=-1)
+gd = graph_of(draw, N, lo_)
+gg = graph_of(gemm, N, hi_)
+
+
+def timed_pair(reps=10):
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(lo_):
+        e[0].record()
+    with torch.cuda.stream(hi_):
+        e[2].record()
+    for _ in range(reps):
+        with torch.cuda.stream(lo_):
+            gd.replay()
+        with torch.cuda.stream(hi_):
+            gg.replay()
+    with torch.cuda.stream(lo_):
+        e[1].record()
+    with torch.cuda.stream(hi_):
+        e[3].record()
+    torch.cuda.synchronize()
+    return e[0].elapsed_time(e[1]) / reps / N * 1e3, e[2].elapsed_time(e[3]) / reps / N * 1e3
+
+
+timed_pair(2)
+td, tg = timed_pair()
+print("priorities (draw low, gemm high), both running: draw stream %.2f us per launch, gemm stream %.2f us per launch" % (td, tg))
