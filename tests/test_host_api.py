@@ -155,6 +155,20 @@ def test_draw_once_entry_points_reject_bad_arguments_without_launching():
     assert b"roundup" in lib.bnn_last_error()
     assert lib.bnn_dense_forward(None, 0, 64, one, 0, 64, None, 0, one, 64, 16, 4, 16, 64, 1, 0, None) == -1
     assert lib.bnn_dense_forward(one, 0, 64, one, 0, 64, None, 0, one, 64, 16, 4, 16, 64, 1, 64, None) == _lib.E_UNSUPPORTED   # unknown flag
+    # fp32 parity mode on three-plane operands: plane strides are checked, a narrow layer writes fp32 only, three-plane draws are
+    # plain draws
+    ok_args = (one, 64 * 64, 0, 64, one, 32 * 64, 32 * 64, 64, None, 0, one, 0, 64 * 32, 32, 64, 32, 64, 1)
+    assert lib.bnn_dense_forward_x3(None, *ok_args[1:], 0, None) == -1
+    bad = list(ok_args); bad[1] = 8                                                     # plane stride < one plane
+    assert lib.bnn_dense_forward_x3(*bad, 0, None) == -2 and b"plane stride" in lib.bnn_last_error()
+    narrow = (one, 64 * 64, 0, 64, one, 16 * 64, 16 * 64, 64, None, 0, one, 64 * 16, 64 * 16, 16, 64, 16, 64, 1)
+    assert lib.bnn_dense_forward_x3(*narrow, _lib.FLAG_Y_BF16, None) == _lib.E_UNSUPPORTED and b"narrow" in lib.bnn_last_error()
+    assert lib.bnn_split_bf16x3(None, 4, 8, 8, one, 64, 256, None) == -1
+    assert lib.bnn_split_bf16x3(one, 4, 12, 12, one, 64, 256, None) == _lib.E_UNSUPPORTED
+    assert lib.bnn_split_bf16x3(one, 0, 8, 8, one, 64, 256, None) == 0                   # no rows: nothing to do
+    t[0].kind, t[0].out_dtype = 1, _lib.BF16X3
+    assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == _lib.E_UNSUPPORTED and b"three-plane" in lib.bnn_last_error()
+    t[0].kind, t[0].out_dtype = 0, _lib.BF16
     sh = _lib.Conv2dShape(B=2, C=48, H=6, W=6, O=64, KH=3, KW=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, dil_h=1, dil_w=1, groups=1)
     assert lib.bnn_conv2d_dense_forward(one, 0, one, 0, 448, None, 0, one, 0, ctypes.byref(sh), 1, 0, None) == _lib.E_UNSUPPORTED
     assert b"C = 64" in lib.bnn_last_error()
