@@ -248,7 +248,8 @@ __device__ __forceinline__ void dma_piece(const void *base, uint32_t voff, uint3
 //                    layers: 4 x 8 x 8 = 256 workgroups (N = 1200 rounds up to 1280: the clamped rows are never stored)
 //   <4, 8, 4, 1, 3>: 256 x 128 tile for wide layers
 // DIAG (BNN_DENSE_DIAG): timing-only builds whose outputs are wrong: 1 = consumers skip reads and MFMAs, 2 = loaders skip the
-// DMA; correct builds for A/B runs of the read interleave: 3 = one MFMA per interleaved fragment read, 4 = two.
+// DMA, 5 = no DMA and no per-step barriers either (2 vs 5 = what the barriers cost: layer 2 13.85 vs 11.9 us, ~200 cycles per
+// step); correct builds for A/B runs of the read interleave: 3 = one MFMA per interleaved fragment read, 4 = two.
 template <int TM, int TN, int NWM, int NWN, int ST, int YM, bool RELU, int DIAG = 0>
 __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
 {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
             constexpr int NBP = decltype(nbp_c)::value;
             constexpr int P = A_PIECES + NBP;           // VMEM ops of this wave per stage
             auto issue = [&](int kt) {
-                if constexpr (DIAG == 2) return;
+                if constexpr (DIAG == 2 || DIAG == 5) return;
                 const int stage = kt % ST;
                 int kb = kt;
                 const char *ab = a_base, *wb = w_base;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
                 if (ST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * P) : "memory");
                 else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();           // barrier kt: stage kt complete; stage (kt - 1) % ST is free
+                if constexpr (DIAG != 5) __builtin_amdgcn_s_barrier();           // barrier kt: stage kt complete; stage (kt - 1) % ST is free
                 if (kt + ST - 1 < nk) issue(kt + ST - 1);
             }
             __builtin_amdgcn_s_barrier();               // final barrier: the consumers reuse the ring for the epilogue
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     };
     auto second_half = [&](uint32_t next) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's reads of stage t have returned
-        __builtin_amdgcn_s_barrier();                   // barrier t + 1
+        if constexpr (DIAG != 5) __builtin_amdgcn_s_barrier();      // barrier t + 1
         asm volatile("" ::: "memory");
         rd(I0{}, next, I0{});                           // (t + 1, h0) -> buffer 0
         if constexpr (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
         interleave();
         __builtin_amdgcn_sched_barrier(0);
     };
-    __builtin_amdgcn_s_barrier();                       // barrier 0
+    if constexpr (DIAG != 5) __builtin_amdgcn_s_barrier();         // barrier 0
     asm volatile("" ::: "memory");
     rd(I0{}, 0u, I0{});
     uint32_t stage = 0;
@@ -991,6 +992,7 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
         else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 2>), g, blk, 0, st, p); \
         else if (diag == 3) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 3>), g, blk, 0, st, p); \
         else if (diag == 4) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 4>), g, blk, 0, st, p); \
+        else if (diag == 5) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 5>), g, blk, 0, st, p); \
         else hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_>), g, blk, 0, st, p); \
     } while (0)
 #define BNN_DENSE_PICK(TN_, NWM_, NWN_, ST_) \
