@@ -582,12 +582,19 @@ def conv_roofline(which, mode, dev, iters=20):
     tag = "conv_%s_%s" % (which, mode)
     traffic, src = pmc_traffic(tag)
     abytes = 4.0 * x.numel() + 4.0 * SAMPLES * B * O * OH * OH + 8.0 * (O * C * k * k + O)
-    return {"kernel": "NormalConv2d %d->%d k%d s%d p%d on %dx%d, batch %d x 8 samples, one layer call (%s)"
-                      % (C, O, k, s, p, HW, HW, B, tag),
-            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK[mode], 4), "traffic": traffic, "traffic_source": src,
-            "avg_launch_us": round(ms * 1e3, 2), "algorithmic_flop_per_launch": flops,
-            "algorithmic_bytes_per_launch": abytes}
+    # which roof: the layer's arithmetic intensity against the machine balance (2.5 PFLOP/s / 8 TB/s = 312 FLOP per byte)
+    intensity = flops / abytes
+    gbs = abytes / (ms * 1e-3) / 1e9
+    out = {"kernel": "NormalConv2d %d->%d k%d s%d p%d on %dx%d, batch %d x 8 samples, one layer call = draw launch + k_conv_bf16 (%s)"
+                     % (C, O, k, s, p, HW, HW, B, tag),
+           "flop_per_algorithmic_byte": round(intensity, 1), "traffic": traffic, "traffic_source": src,
+           "avg_launch_us": round(ms * 1e3, 2), "algorithmic_flop_per_launch": flops, "algorithmic_bytes_per_launch": abytes,
+           "tflops": round(ach, 2), "gbytes_per_s": round(gbs, 1)}
+    if intensity < PEAK[mode] * 1e12 / (PEAK_HBM_GBS * 1e9):
+        out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    else:
+        out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s", "frac": round(ach / PEAK[mode], 4)})
+    return out
 
 
 def wide_roofline(dev, iters=5):
