@@ -425,12 +425,14 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     // (block scheduling: the reads-then-MFMAs order cost ~250 cycles of a 900-cycle step with the MFMA pipe idle).
     auto interleave = [&]() {
         if constexpr ((DIAG == 0 || DIAG >= 3) && INTERLEAVE) {
+            constexpr int NI = (TM * TN) / MPR < TM + TN ? (TM * TN) / MPR : TM + TN;   // reads that get MFMAs in front of them
 #pragma unroll
-            for (int i = 0; i < TM + TN; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);    // MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - MPR * (TM + TN), 0);
+            if constexpr (TM + TN > NI) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN - NI, 0);
+            if constexpr (TM * TN > MPR * NI) __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - MPR * NI, 0);
         }
     };
     auto first_half = [&](uint32_t stage) {
@@ -970,13 +972,23 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
     if (no_xcd) p.flags |= kDenseNoXcdMap;
     // tile: the BASELINE-shaped layers (N % 80 == 0: 1200 = 7.5 x 160) take 128 x 160 with a 4-stage ring -- 36 KiB per
     // 64-k step instead of 256 x 80's 42 for the same MFMAs, 4 x 8 x 8 = 256 workgroups; wide layers 256 x 128.
-    // BNN_DENSE_TILE = 0 (256 x 80), 1 (128 x 160), 2 (256 x 128) forces one for A/B runs.
+    // BNN_DENSE_TILE = 0 (256 x 80), 1 (128 x 160), 2 (256 x 128), 3 (64 x 160), 4 (32 x 160) forces one for A/B runs.
     static const int force_tile = [] { const char *e = getenv("BNN_DENSE_TILE"); return e ? atoi(e) : -1; }();
     int tile = (N % 80 == 0 || N < 128) ? 1 : 2;
     if (N <= 80) tile = 0;
-    if (force_tile >= 0 && force_tile <= 2) tile = force_tile;
-    const int bm = tile == 1 ? 128 : 256;
-    const int bn = tile == 0 ? 80 : tile == 1 ? 160 : 128;
+    if (force_tile >= 0 && force_tile <= 4) tile = force_tile;
+    // few samples (a rank of a sharded MC job runs 8 / G of them): 64- and 32-row versions of the 128 x 160 tile, the largest
+    // that still gives >= 128 workgroups -- a dense launch over ONE sample (32 workgroups) took as long as over eight.
+    // Measured at the BASELINE layers, one stream / three steps in flight, us per step: 4 samples 54.2 / 28.3 (128 rows),
+    // 51.0 / 30.9 (64), 58.7 / 37.4 (32); 2 samples 48.8 / 22.3, 44.3 / 20.8, 41.9 / 24.0; 1 sample 46.2 / 19.3, 41.3 / 17.8,
+    // 39.0 / 17.9: with the chip already full of other steps' work the bigger tile wins (fewer re-reads of the weights).
+    if (tile == 1 && force_tile < 0) {
+        const int64_t cols = (N + 159) / 160;
+        if (((M + 127) / 128) * cols * nsamples < 128 && M > 64) tile = 3;
+        if (tile == 3 && ((M + 63) / 64) * cols * nsamples < 128 && M > 32) tile = 4;
+    }
+    const int bm = tile == 1 ? 128 : tile == 3 ? 64 : tile == 4 ? 32 : 256;
+    const int bn = tile == 0 ? 80 : tile == 2 ? 128 : 160;
     p.ntm = (int32_t)((M + bm - 1) / bm);
     p.ntn = (int32_t)((N + bn - 1) / bn);
     const int64_t grid = (int64_t)p.ntm * p.ntn * nsamples;
@@ -984,24 +996,26 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
     static const int diag = [] { const char *e = getenv("BNN_DENSE_DIAG"); return e ? atoi(e) : 0; }();
     const bool relu = (flags & BNN_FLAG_RELU) != 0;
     const dim3 g((unsigned)grid), blk(512);
-#define BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, RELU_) \
+#define BNN_DENSE_LAUNCH(TM_, TN_, NWM_, NWN_, ST_, RELU_) \
     do { \
-        if (x3 && ybf) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 2, RELU_>), g, blk, 0, st, p); \
-        else if (!ybf) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 0, RELU_>), g, blk, 0, st, p); \
-        else if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 1>), g, blk, 0, st, p); \
-        else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 2>), g, blk, 0, st, p); \
-        else if (diag == 3) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 3>), g, blk, 0, st, p); \
-        else if (diag == 4) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 4>), g, blk, 0, st, p); \
-        else if (diag == 5) hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_, 5>), g, blk, 0, st, p); \
-        else hipLaunchKernelGGL((k_dense_bf16<4, TN_, NWM_, NWN_, ST_, 1, RELU_>), g, blk, 0, st, p); \
+        if (x3 && ybf) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 2, RELU_>), g, blk, 0, st, p); \
+        else if (!ybf) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 0, RELU_>), g, blk, 0, st, p); \
+        else if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 1>), g, blk, 0, st, p); \
+        else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 2>), g, blk, 0, st, p); \
+        else if (diag == 3) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 3>), g, blk, 0, st, p); \
+        else if (diag == 4) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 4>), g, blk, 0, st, p); \
+        else if (diag == 5) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 5>), g, blk, 0, st, p); \
+        else hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_>), g, blk, 0, st, p); \
     } while (0)
-#define BNN_DENSE_PICK(TN_, NWM_, NWN_, ST_) \
+#define BNN_DENSE_PICK(TM_, TN_, NWM_, NWN_, ST_) \
     do { \
-        if (relu) BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, true); else BNN_DENSE_LAUNCH(TN_, NWM_, NWN_, ST_, false); \
+        if (relu) BNN_DENSE_LAUNCH(TM_, TN_, NWM_, NWN_, ST_, true); else BNN_DENSE_LAUNCH(TM_, TN_, NWM_, NWN_, ST_, false); \
     } while (0)
-    if (tile == 0) BNN_DENSE_PICK(5, 4, 1, 3);
-    else if (tile == 1) BNN_DENSE_PICK(5, 2, 2, 4);
-    else BNN_DENSE_PICK(8, 4, 1, 3);
+    if (tile == 0) BNN_DENSE_PICK(4, 5, 4, 1, 3);
+    else if (tile == 1) BNN_DENSE_PICK(4, 5, 2, 2, 4);
+    else if (tile == 3) BNN_DENSE_PICK(2, 5, 2, 2, 4);
+    else if (tile == 4) BNN_DENSE_PICK(1, 5, 2, 2, 4);
+    else BNN_DENSE_PICK(4, 8, 4, 1, 3);
 #undef BNN_DENSE_PICK
 #undef BNN_DENSE_LAUNCH
     return check_launch(who);

@@ -100,6 +100,11 @@ DENSE_SHAPES = [  # S, M, N, K, shared_x, relu, y_bf16
     (3, 40, 16, 2048, True, True, False),
     (1, 1, 10, 8, False, False, False),
     (2, 260, 256, 320, False, False, False),      # 128-column tiles
+    (4, 512, 1200, 1200, False, True, True),      # a rank of a 2-GPU job: 64 x 160 tiles
+    (2, 512, 1200, 784, True, True, True),        # ... of a 4-GPU job: 32 x 160 tiles
+    (1, 512, 1200, 1200, False, True, False),     # ... of an 8-GPU job
+    (1, 100, 160, 72, True, False, False),        # 64-row tiles with a ragged last tile
+    (1, 48, 240, 200, False, True, True),         # 32-row tiles, ragged rows
 ]
 
 

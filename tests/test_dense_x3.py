@@ -76,6 +76,8 @@ X3_SHAPES = [  # S, M, N, K, shared, relu, planes_out
     (1, 64, 48, 8, True, True, True),
     (3, 130, 170, 200, False, False, True),
     (1, 300, 4096, 256, True, False, False),
+    (1, 512, 1200, 784, True, True, True),         # one sample: 32 x 160 tiles
+    (4, 512, 1200, 1200, False, True, False),      # four: 64 x 160
     (8, 512, 10, 1200, False, False, False),       # the classifier head: K-split kernel, six passes
     (2, 70, 16, 2048, True, True, False),
 ]

@@ -11,7 +11,7 @@ bnn.manual_seed(2); bnn.set_compute("bf16")
 net = bench.build_net(dev, bench.posteriors(0))
 x = bench.resident_input(torch.randn(bench.BATCH, bench.DIMS[0]).to(dev), "bf16")
 base = None
-for G in (1, 2, 4, 8):
+for G in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
     cnt = bench.SAMPLES // G
     kw = dict(samples=cnt, sample0=0, total_samples=bench.SAMPLES)
     st = bench.Step(net, x, 0, 1, True, **kw)
