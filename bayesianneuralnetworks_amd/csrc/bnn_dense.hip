@@ -4,7 +4,7 @@
 //       S MC samples, written as bf16 rows zero-padded to a multiple of 64 columns (biases: fp32) -- optionally
 //       carrying the KL's first pass as extra workgroups (it reads the same mu / rho);
 //   (2) k_dense_bf16 : y[s] = act(x[s] . w_s^T + b_s) on the drawn weights -- a dense MFMA GEMM whose operands both
-//       arrive by LDS-DMA;
+//       arrive by LDS-DMA (bf16 operands, or three bf16 planes per operand for the fp32 parity mode);
 //   (3) k_head_bf16  : the same contraction for N <= 16 (the classifier head), K split over the waves of a workgroup.
 //
 // Why not fused (bnn_linear.hip draws inside the GEMM): one Philox block + Box-Muller + softplus is ~150 VALU issue
@@ -14,24 +14,24 @@
 // S samples of a weight (softplus: 36 of the ~150 slots), and the contraction becomes a GEMM bound by the L2 -> LDS
 // DMA rate and the MFMA pipe.  The 2 bytes per drawn weight this writes and re-reads stay in L2 / Infinity Cache.
 //
-// k_dense_bf16 structure (MI355X: 160 KB LDS, LDS-DMA, 4 SIMDs per CU):
-//   * 4 waves per workgroup (one per SIMD), all along M: wave w owns rows [w * 16 TM, (w + 1) * 16 TM) x all 16 TN
-//     columns of the tile.  Its A rows go into a PRIVATE 3-stage LDS ring filled by its own LDS-DMA pieces, so the
-//     only synchronisation on A is the wave's own counted s_waitcnt vmcnt.
-//   * the B tile (16 TN weight rows x 64 k) is shared: every wave DMAs a quarter of it, one raw s_barrier per 64-k
-//     step makes the four quarters visible (and frees the stage that is refilled next).
-//   * stages are requested two k-steps ahead: at the top of step t a wave waits for ITS pieces of step t
-//     (vmcnt(P): step t + 1's P pieces stay in flight), meets the barrier, issues step t + 2, computes step t.
+// k_dense_bf16 structure (MI355X: 160 KB LDS, LDS-DMA, 4 SIMDs per CU) -- details at the kernel:
+//   * 8 waves per workgroup, two roles: waves 0-3 consume (an NWM x NWN grid of 16 TM x 16 TN wave tiles: fragment reads,
+//     MFMAs, epilogue), waves 4-7 load (LDS-DMA of both operands, 1-KiB pieces taken round-robin).  One raw s_barrier per
+//     64-k step, met by all eight waves, is the only hand-off; stages are requested ST - 1 steps ahead and waited for with
+//     counted s_waitcnt vmcnt.
+//   * tiles: 128 x 160 with a 4-stage ring (the BASELINE layers: 256 workgroups), 64 / 32 x 160 for launches over few
+//     samples, 256 x 128 with 3 stages (wide layers), 256 x 80.
 //   * LDS image of both operands: [row][8 x 16 B] with 16-B chunk c of row r at position c ^ (r & 7); the DMA writes
 //     linearly (lane l -> position l & 7 of row l >> 3 of its 8-row piece), so lane l FETCHES chunk (l & 7) ^ (l >> 3):
 //     eight lanes read one whole 128-B line.  ds_read_b128 fragment reads of this image are conflict-free.
 //   * v_mfma_f32_16x16x32_bf16; lane (i = l & 15, q = l >> 4) holds k = 8 q .. 8 q + 7 of a 32-k half-step = chunk
-//     4 h + q of the row: the DMA'd 16 B ARE the fragment.
+//     4 h + q of the row: the DMA'd 16 B ARE the fragment.  Fragment reads are interleaved into the MFMA stream.
 //   * K tail: A's chunk address is clamped inside the row (finite data), the weights are ZERO there (padded rows).
 //   * XCD map: blockIdx % 8 = MC sample (mod 8): a sample's activations and drawn weights (1.2 + 2.9 MB at the
 //     BASELINE layer) live in one XCD's 4 MB L2.
-//   * epilogue: bias, optional ReLU, then the wave's 16 TM x 16 TN results leave through its own A ring as whole
-//     16-B row chunks.
+//   * epilogue: bias, optional ReLU, then each wave's results leave through its quarter of the ring as whole 16-B row chunks
+//     -- fp32, bf16, or the three bf16 planes of the fp32 result.
+//   * fp32 parity mode: every operand as three bf16 planes, six plane-pair k-steps per k-block (bnn_dense_forward_x3).
 #include <cstdlib>
 #include <type_traits>
 
