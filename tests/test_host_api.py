@@ -376,3 +376,31 @@ def test_gradient_reducer_rejects_non_fp32_parameters():
     from bayesianneuralnetworks_amd import distributed as bd
     with pytest.raises(TypeError):
         bd.GradAllReducer([torch.nn.Parameter(torch.ones(2, dtype=torch.float64))])
+
+
+def test_fuse_activations_marks_compute_format_hand_overs_and_x3_round_trip():
+    """nn.fuse_activations(bf16_activations=True): a fused NormalLinear that feeds another NormalLinear may hand its hidden
+    activation on in the compute format (bf16 in 'bf16' mode, three bf16 planes in the 'f32' mode); the last layer may not.
+    ops.X3Activation.float() is the exact three-term sum (host logic, CPU tensors)."""
+    import torch
+    from bayesianneuralnetworks_amd import ops
+    from bayesianneuralnetworks_amd.nn import NormalLinear, fuse_activations
+    seq = torch.nn.Sequential(NormalLinear(16, 32), torch.nn.ReLU(), NormalLinear(32, 24), torch.nn.ReLU(), NormalLinear(24, 10))
+    assert fuse_activations(seq, bf16_activations=True) == 2
+    l1, l2, l3 = seq[0], seq[2], seq[4]
+    assert l1.activation == l2.activation == 'relu' and l3.activation is None
+    assert isinstance(seq[1], torch.nn.Identity) and isinstance(seq[3], torch.nn.Identity)
+    assert l1.out_dtype == torch.bfloat16 and l2.out_dtype == torch.bfloat16
+    assert l1.out_x3 and l2.out_x3                      # both consumers can read planes (the 10-wide head: K = 24 <= 2048)
+    assert not getattr(l3, "out_x3", False)
+    v = torch.randn(6, 40) * torch.logspace(-3, 3, 40)
+    h = v.bfloat16()
+    r = v - h.float()
+    m = r.bfloat16()
+    l = (r - m.float()).bfloat16()
+    planes = torch.zeros(3, 2, 3, 64, dtype=torch.bfloat16)
+    planes[:, :, :, :40] = torch.stack([h, m, l]).reshape(3, 2, 3, 40)
+    act = ops.X3Activation(planes, 40)
+    assert act.shape == (6, 40) and act.dim() == 2 and not act.is_cuda
+    back = act.float()
+    assert back.shape == (6, 40) and (back - v).abs().max() <= v.abs().max() * 2.0 ** -23
