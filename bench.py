@@ -729,7 +729,7 @@ def main(argv=None):
     ap.add_argument("--mode", default="forward", choices=["forward", "train"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1 headline: strong = the 8 global MC samples sharded 8/N per GPU (SURVEY 8e); weak = 8 per GPU")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BNN_BENCH_INFLIGHT", "3")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BNN_BENCH_INFLIGHT", "4")),
                     help="N = 1 forward: independent steps in flight on separate streams (1 = one stream)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
