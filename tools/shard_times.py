@@ -16,10 +16,10 @@ for G in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
     kw = dict(samples=cnt, sample0=0, total_samples=bench.SAMPLES)
     st = bench.Step(net, x, 0, 1, True, **kw)
     t1 = bench.time_steps(st, 1000, 200, 1, dev) / 1000
-    pipe = bench.PipelinedSteps(net, x, 3, **kw)
+    pipe = bench.PipelinedSteps(net, x, 4, **kw)
     t3 = bench.time_steps(pipe, 1000, 200, 1, dev) / 1000
     rate = bench.SAMPLES / t3
     base = rate if base is None else base
-    print("G = %d (%d samples per rank): one stream %.1f us per step, 3 in flight %.1f us -> a %d-GPU job at best %.0f k MC-samples/s = %.2f of %d x the 1-GPU rate"
+    print("G = %d (%d samples per rank): one stream %.1f us per step, 4 in flight %.1f us -> a %d-GPU job at best %.0f k MC-samples/s = %.2f of %d x the 1-GPU rate"
           % (G, cnt, t1 * 1e6, t3 * 1e6, G, rate / 1e3, rate / (G * base), G))
     del st, pipe
