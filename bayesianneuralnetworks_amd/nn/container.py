@@ -101,7 +101,8 @@ class BayesianNetworkModule(Module):
         """bf16 compute mode: the posteriors of EVERY NormalLinear of the network are drawn for this forward's S samples
         in ONE launch (ops.draw_layers -> bnn_draw_multi) before `_forward` runs; each layer then finds its drawn
         weights (consumed on first use: a layer called twice draws again, like the reference's per-call sample(),
-        dense.py:56-58).  Keys are recorded per layer exactly as layer.sample() would.  Returns the layers it drew for."""
+        dense.py:56-58).  The plan itself leaves the layers' state alone: the keys travel in the Predrawn entry and a layer
+        records them -- exactly as its own sample() would -- when it uses the entry.  Returns the layers it drew for."""
         from .. import ops
         from . import _settings
         from .dense import NormalLinear
@@ -121,10 +122,12 @@ class BayesianNetworkModule(Module):
             return []
 
         def specs_of(mods):
+            # The plan draws on FRESH keys but does not touch the layers: a layer adopts its keys only when it consumes the
+            # drawn weights with sample=True (NormalLinear.forward); one called with sample=False, or never reached by
+            # `_forward`, keeps its recorded draw or its user-assigned `.sampled` (dense.py:56-58: `if sample: self.sample()`).
             specs = []
             for m in mods:
-                m.sample(ctx.samples, ctx.sample0)
-                kw, kb = m._keys(ctx.samples)
+                kw, kb = m._fresh_keys(ctx.samples, ctx.sample0)
                 specs.append((m.weight.mean.detach(), m.weight.scale.detach(),
                               m.bias.mean.detach() if m.bias is not None else None,
                               m.bias.scale.detach() if m.bias is not None else None, kw, kb))

@@ -1,8 +1,11 @@
 """Dense Bayesian layers (pytorch_bayesian/nn/dense.py).
 
-NormalLinear is the hot path: on a CUDA/HIP input its forward is ONE fused kernel
-(bnn_linear_forward_sampled): eps draw + w = mu + softplus(rho) * eps in the B-operand
-loader of an MFMA GEMM.  The other classes (Flipout, multivariate, evidential, MC-dropout)
+NormalLinear is the hot path.  On a CUDA/HIP input its forward is draw once + dense GEMM: the posterior is drawn for
+all S MC samples of the call by bnn_draw_multi (ONE launch for every NormalLinear of a network when a
+BayesianNetworkModule's draw plan runs first), then contracted by bnn_dense_forward (bf16 mode: bf16 operands, fp32
+accumulate) or bnn_dense_forward_x3 (fp32 parity mode at inference: three bf16 planes per operand).  Training-time fp32
+forwards, narrow fp32 layers and A/B runs take the round-1 fused kernel (bnn_linear_forward_sampled: the draw inside the
+B-operand loader of the GEMM).  The other classes (Flipout, multivariate, evidential, MC-dropout)
 are outside the HIP scope and run as PyTorch-ROCm ops with the
 reference's semantics so that its examples keep working.
 """
@@ -60,6 +63,20 @@ class _NormalSampling:
         self.weight.sample(nsamples, sample0, epoch)
         if self.bias is not None:
             self.bias.sample(nsamples, sample0, epoch)
+
+    def _fresh_keys(self, nsamples, sample0):
+        """The DrawKeys sample(nsamples, sample0) would record, without recording them (the network's draw plan draws on
+        them ahead of the layer's call; _adopt_keys records them when the layer uses that draw)."""
+        from .._rng import DrawKey
+        epoch = default_generator.next_epoch()
+        kw = DrawKey(default_generator.seed, self.weight._stream, sample0, nsamples, epoch)
+        kb = DrawKey(default_generator.seed, self.bias._stream, sample0, nsamples, epoch) if self.bias is not None else None
+        return kw, kb
+
+    def _adopt_keys(self, kw, kb):
+        self.weight._key, self.weight._explicit = kw, None
+        if self.bias is not None:
+            self.bias._key, self.bias._explicit = kb, None
 
     @property
     def sampled(self):
@@ -145,6 +162,7 @@ class NormalLinear(_NormalSampling, BayesianLinear):
             self._predrawn = None
             if sample and pd[0] is _mc.current():
                 predrawn, sample = pd[1], False
+                self._adopt_keys(predrawn.key_w, predrawn.key_b)        # this call's sample(): the plan drew on these keys
         S, _, shared, per = self._mc_plan(x, sample)
         keys = self._keys(S)
         mode = self._compute_mode()

@@ -233,15 +233,29 @@ def draw_layers(layers, nsamples, kl=None, stream=None, x3=False):
     return out
 
 
+def rows_pitch(t, K):
+    """A (M, K) or (S, M, K) bf16 activation whose rows the dense kernel can read in place -- unit element stride, one row
+    pitch (>= K, whole 16-B chunks), samples a whole number of 16-B chunks apart, e.g. the 128-B-aligned rows _dense_raw
+    itself writes -> (row pitch, sample stride) in elements, the values to LAUNCH with; None if the view is not of that kind.
+    The strides are read off the view, never re-derived from M and K: with one row per sample the row stride of the view says
+    nothing (torch may report anything for a size-1 dimension) and the samples of a padded (S, 1, K) view sit stride(0)
+    apart, not K."""
+    if t.dtype != torch.bfloat16 or t.dim() not in (2, 3) or t.shape[-1] != K or t.stride(-1) != 1 or t.data_ptr() % 16 != 0:
+        return None
+    M = t.shape[-2]
+    ld = t.stride(-2) if M > 1 else K               # a single row: its pitch is never used to step to another row
+    if ld < K or ld % 8 != 0:
+        return None
+    if t.dim() == 2 or t.shape[0] == 1:
+        return ld, M * ld
+    xs = t.stride(0)
+    if xs % 8 != 0 or xs < (M - 1) * ld + K:        # samples overlap, or are not 16-B aligned
+        return None
+    return ld, xs
+
+
 def rows_regular(t, K):
-    """A (M, K) or (S, M, K) bf16 activation whose rows the dense kernel can read in place: unit element stride, one row
-    pitch (>= K, whole 16-B chunks), samples M rows apart -- e.g. the 128-B-aligned rows _dense_raw itself writes."""
-    if t.dtype != torch.bfloat16 or t.dim() not in (2, 3) or t.shape[-1] != K or t.stride(-1) != 1:
-        return False
-    ld = t.stride(-2) if t.shape[-2] > 1 else max(K, t.stride(-2))
-    if ld < K or ld % 8 != 0 or t.data_ptr() % 16 != 0:
-        return False
-    return t.dim() == 2 or t.shape[0] == 1 or t.stride(0) == t.shape[1] * ld
+    return rows_pitch(t, K) is not None
 
 
 def _dense_raw(x2, x_sample_stride, M, pre, K, relu, out_dtype, ldx=None, pad_rows=False):
@@ -372,10 +386,10 @@ def _linear_sampled_raw(x2, x_sample_stride, M, mu_w, rho_w, mu_b, rho_b, key_w,
             if _tls.kl_carry is not None and _tls.kl_carry.launched:
                 _tls.kl_carry = None
         pre.wait()
-        if x2.dtype == torch.bfloat16 and rows_regular(x2, K):
-            ldx = x2.stride(-2) if M > 1 else K
-            xs = 0 if x_sample_stride == 0 else M * ldx
-            return _dense_raw(x2, xs, M, pre, K, relu, out_dtype, ldx=ldx, pad_rows=pad_rows)
+        pitch = rows_pitch(x2, K) if x2.dtype == torch.bfloat16 else None
+        if pitch is not None:
+            ldx, xs = pitch
+            return _dense_raw(x2, 0 if x_sample_stride == 0 else xs, M, pre, K, relu, out_dtype, ldx=ldx, pad_rows=pad_rows)
         xb = x2.contiguous().to(torch.bfloat16)        # (the fused kernel rounds its A operand the same way)
         return _dense_raw(xb, x_sample_stride, M, pre, K, relu, out_dtype, pad_rows=pad_rows)
     x2 = x2.contiguous()
@@ -913,8 +927,10 @@ def conv2d_flipout(x, mean, scale, R, S, stride, padding, dilation):
     kp = w2.shape[1]
     sh, OH, OW = _conv_shape(x.shape, mean.shape, stride, padding, dilation, 1)
     y = torch.empty((sh.B, O, OH, OW), dtype=torch.float32, device=dev)
-    Sf = S.reshape(sh.B, C).to(torch.float32).contiguous()
-    Rf = R.reshape(sh.B, O).to(torch.float32).contiguous()
+    # the sign tensors broadcast over the batch like the reference's expand_as (conv.py:207-221): drawn for another batch size
+    # (sample=False after the constructor's sample(1)) a (1, C, 1, 1) tensor serves every image
+    Sf = S.to(torch.float32).expand(sh.B, C, 1, 1).reshape(sh.B, C).contiguous()
+    Rf = R.to(torch.float32).expand(sh.B, O, 1, 1).reshape(sh.B, O).contiguous()
     check(lib.bnn_conv2d_flipout_forward(ptr(x), ptr(w2), kp, ptr(Sf), ptr(Rf), ptr(y), ctypes.byref(sh), 0, stream_ptr(dev)),
           "bnn_conv2d_flipout_forward")
     return y

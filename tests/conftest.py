@@ -43,3 +43,17 @@ def allclose_scaled(x, ref, tol=1e-5):
     ref = np.asarray(ref, dtype=np.float64)
     scale = max(1.0, float(np.sqrt((ref ** 2).mean())))
     return bool((np.abs(x - ref) <= tol * scale + tol * np.abs(ref)).all())
+
+
+def assert_close_scaled(x, ref, tol=1e-5, what=""):
+    """allclose_scaled that ASSERTS (a bare allclose_scaled(...) call checks nothing) and reports the worst element."""
+    x = np.asarray(x, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert x.shape == ref.shape, (what, x.shape, ref.shape)
+    scale = max(1.0, float(np.sqrt((ref ** 2).mean())))
+    excess = np.abs(x - ref) - (tol * scale + tol * np.abs(ref))
+    worst = int(np.argmax(excess))
+    assert bool((excess <= 0).all()), "%s: max |err| %.3e (allowed %.3e at that element, output scale %.3g, %d of %d elements out)" % (
+        what, float(np.abs(x - ref).reshape(-1)[worst]), float((tol * scale + tol * np.abs(ref)).reshape(-1)[worst]), scale,
+        int((excess > 0).sum()), excess.size)
+    return float(np.abs(x - ref).max() / scale)

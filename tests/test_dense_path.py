@@ -393,3 +393,95 @@ def test_flipout_conv_fused_kernel_vs_oracle(env, B, C, O, HW, k, st, pad):
     assert allclose_scaled(got, want), np.abs(got - want).max()
     rms = float(np.sqrt((N(y32) ** 2).mean()))
     assert np.abs(N(y) - N(y32)).max() <= 2e-2 * max(1.0, rms)     # bf16 operands against fp32 operands
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_draw_plan_leaves_layer_state_alone_for_sample_false(env, mode):
+    """`_forward` calling a layer with sample=False must reuse the user-assigned `.sampled` (dense.py:56-58:
+    `if sample: self.sample()`) on the batched path too -- the plan draws ahead of the call but must not re-key the layer --
+    and a layer `_forward` never reaches keeps its recorded draw.  Batched path == serial loop."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule
+    dev = env["dev"]
+    torch.manual_seed(14)
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(64, 16, 3)
+            self.a = NormalLinear(64, 80)
+            self.frozen = NormalLinear(80, 24)
+            self.unused = NormalLinear(24, 24)
+
+        def _forward(self, x):
+            return self.frozen(torch.relu(self.a(x)), sample=False)
+
+    net = Net().to(dev)
+    w = torch.randn(24, 80, device=dev) * 0.1
+    b = torch.randn(24, device=dev)
+    x = torch.randn(70, 64, device=dev)
+    bnn.set_compute(mode)
+    try:
+        bnn.manual_seed(5)
+        net.unused.sample()
+        key_unused = net.unused.weight.draw_key
+        net.frozen.sampled = (w, b)
+        with torch.no_grad():
+            net.mc_batched = True
+            ys = net.forward_stacked(x, 3)
+            assert net.frozen.weight._explicit is w and net.frozen.bias._explicit is b      # still the assigned weights
+            assert net.unused.weight.draw_key is key_unused                                 # never reached: not re-keyed
+            assert net.a.weight.draw_key.nsamples == 3                                      # consumed its planned draw
+            ha = torch.relu(_layer_outputs(env, net.a, x, 3, mode))                         # (3, 70, 80) on the recorded keys
+        want = ha.double() @ w.double().T + b.double()
+        tol = 1e-5 if mode == "f32" else 2.0 ** -7
+        err = (ys.double() - want).abs().max().item()
+        assert err <= tol * max(1.0, want.pow(2).mean().sqrt().item()), err
+        # no two samples alike (layer a was drawn per sample), and the serial loop agrees on what `frozen` does
+        assert not torch.equal(ys[0], ys[1])
+        net.mc_batched = False
+        with torch.no_grad():
+            y_serial = net.forward(x, 1)
+        assert net.frozen.weight._explicit is w
+        ha1 = torch.relu(_layer_outputs(env, net.a, x, 1, mode))[0]
+        want1 = ha1.double() @ w.double().T + b.double()
+        assert (y_serial.double() - want1).abs().max().item() <= tol * max(1.0, want1.pow(2).mean().sqrt().item())
+    finally:
+        bnn.set_compute("f32")
+
+
+def _layer_outputs(env, layer, x, S, mode):
+    """layer(x) for every sample of the layer's RECORDED draw key, from the standalone sampler (K1) in float64."""
+    ops = env["ops"]
+    kw, kb = layer.weight.draw_key, layer.bias.draw_key
+    w = ops._sample_affine_philox_raw(layer.weight.mean.detach(), layer.weight.scale.detach(), kw)
+    b = ops._sample_affine_philox_raw(layer.bias.mean.detach(), layer.bias.scale.detach(), kb)
+    xx = x
+    if mode == "bf16":
+        w, xx = w.bfloat16().float(), x.bfloat16().float()
+    w = w.reshape(-1, *layer.weight.mean.shape)[-S:]
+    b = b.reshape(-1, layer.bias.mean.shape[0])[-S:]
+    return (torch.einsum("mk,snk->smn", xx.double(), w.double()) + b.double().unsqueeze(1)).float()
+
+
+def test_single_row_samples_chain_through_padded_rows(env):
+    """M = 1 row per sample, S > 1, N = 1200 (row pitch 1216): a dense call's padded bf16 output fed straight into
+    the next dense call -- the (S, 1, K) view has strides (ldy, ldy, 1) and sample s must be read ldy elements on, not K."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    ops, dev = env["ops"], env["dev"]
+    S = 4
+    m1 = _post((1200, 784), 31, dev)
+    m2 = _post((1200, 1200), 32, dev)
+    k1 = (DrawKey(7, 21, 0, S, 3), DrawKey(7, 22, 0, S, 3))
+    k2 = (DrawKey(7, 23, 0, S, 3), DrawKey(7, 24, 0, S, 3))
+    x = torch.randn(1, 784, device=dev).bfloat16()
+    with torch.no_grad():
+        h = ops.linear_sampled(x, *m1, *k1, True, "bf16", relu=True, out_dtype=torch.bfloat16)         # (S, 1, 1200)
+        assert h.shape == (S, 1, 1200)
+        y = ops.linear_sampled(h, *m2, *k2, False, "bf16", relu=False, out_dtype=torch.float32)
+        hc = h.contiguous()
+        y_ref = ops.linear_sampled(hc, *m2, *k2, False, "bf16", relu=False, out_dtype=torch.float32)
+    assert torch.equal(y, y_ref)
+    w2 = ops._sample_affine_philox_raw(m2[0], m2[1], k2[0]).bfloat16().double()
+    b2 = ops._sample_affine_philox_raw(m2[2], m2[3], k2[1]).double()
+    want = torch.einsum("smk,snk->smn", hc.double(), w2) + b2.unsqueeze(1)
+    assert (y.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.pow(2).mean().sqrt().item())

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import allclose_scaled
+from conftest import assert_close_scaled
 import seeded
 
 pytestmark = pytest.mark.gpu
@@ -80,7 +80,24 @@ X3_SHAPES = [  # S, M, N, K, shared, relu, planes_out
     (4, 512, 1200, 1200, False, True, False),      # four: 64 x 160
     (8, 512, 10, 1200, False, False, False),       # the classifier head: K-split kernel, six passes
     (2, 70, 16, 2048, True, True, False),
+    # the 256 x 128 tile (k_dense_bf16<4, 8, 4, 1, 3>: N >= 128 and N % 80 != 0) on three-plane operands -- the instantiation
+    # bench.py's roofline_wide_f32 leg times (configs[4]: 4096 x 4096 at batch 4096), checked on rows of every kind of tile
+    (1, 4096, 4096, 4096, True, False, False),
+    (1, 4096, 4096, 4096, True, True, True),
+    (2, 300, 264, 328, False, True, False),        # ragged M, N and a K tail (328 = 5 x 64 + 8) on that tile
+    (3, 257, 136, 72, True, False, True),
+    (2, 90, 1200, 520, False, True, True),         # 64 x 160 tiles, ragged, K tail, planes out
+    (1, 40, 240, 136, True, False, False),         # 32 x 160
 ]
+
+
+def _check_rows(M):
+    """Rows compared against float64: all of them up to 600, else whole 16-row groups from both ends, the middle, and around
+    every 256- and 128-row tile seam nearby (the CPU einsum in double over 4096 x 4096 x 4096 would take minutes)."""
+    if M <= 600:
+        return torch.arange(M)
+    picks = [0, 112, 240, 256, 1008, 1024, 2040, 2048 + 128, M - 272, M - 16]
+    return torch.cat([torch.arange(r, r + 16) for r in picks])
 
 
 @pytest.mark.parametrize("S,M,Nn,K,shared,relu,planes_out", X3_SHAPES)
@@ -97,24 +114,30 @@ def test_dense_x3_vs_double(env, S, M, Nn, K, shared, relu, planes_out):
     xp = ops.split_x3(x.reshape(-1, K))
     if not shared:
         xp = xp.view(3, S, M, xp.shape[3])
+    n0 = env["lib"].bnn_launch_count()
     y = ops._dense_raw_x3(xp, shared, M, pre, K, relu, planes_out)
+    assert env["lib"].bnn_launch_count() == n0 + 1
     if planes_out:
         assert isinstance(y, ops.X3Activation) and y.planes.shape[:3] == (3, S, M)
         got = y.float().reshape(S, M, Nn)
     else:
         got = y
-    xd = x.double() if not shared else x.double().unsqueeze(0).expand(S, M, K)
-    want = torch.einsum("smk,snk->smn", xd, w.double()) + b.double().unsqueeze(1)
+    rows = _check_rows(M)
+    xd = x.double().cpu() if not shared else x.double().cpu().unsqueeze(0).expand(S, M, K)
+    want = torch.einsum("smk,snk->smn", xd[:, rows], w.double().cpu()) + b.double().cpu().unsqueeze(1)
     if relu:
         want = want.clamp_min(0)
-    allclose_scaled(N(got), want.cpu().numpy(), 1e-5)
+    assert_close_scaled(N(got[:, rows.to(dev)]), want.numpy(), 1e-5, "x3 dense %s" % ((S, M, Nn, K),))
     if planes_out:
-        # the planes are the split of the kernel's own fp32 result: re-splitting their sum reproduces them
+        # the planes are the split of an fp32 value: plane 0 is its bf16 rounding, plane 1 the rounding of what is left, ...
         v = y.float().reshape(S, M, Nn)
         h = v.bfloat16()
         r = v - h.float()
         assert torch.equal(y.planes[0, ..., :Nn], h) and torch.equal(y.planes[1, ..., :Nn], r.bfloat16())
         assert torch.equal(y.planes[2, ..., :Nn], (r - r.bfloat16().float()).bfloat16())
+        # ... and the three planes carry the result to fp32 precision: against float64 directly, in double
+        p64 = (y.planes[0].double() + y.planes[1].double() + y.planes[2].double())[..., :Nn]
+        assert_close_scaled(p64[:, rows.to(dev)].cpu().numpy(), want.numpy(), 1e-5, "x3 planes")
 
 
 def test_dense_x3_argument_errors(env):
@@ -185,7 +208,7 @@ def test_fp32_mode_network_on_dense_path_equals_fused_kernels_and_oracle(env, di
     finally:
         ops.DENSE_X3_F32 = saved
         bnn.set_compute(old_mode)
-    allclose_scaled(N(outs[True]), N(outs[False]), 2e-5)
+    assert_close_scaled(N(outs[True]), N(outs[False]), 2e-5, "dense path vs fused kernels")
     # oracle on the recorded keys (sample by sample, double accumulation)
     keys = outs[(True, "keys")]
     xs = N(x)[:48]
@@ -200,4 +223,5 @@ def test_fp32_mode_network_on_dense_path_equals_fused_kernels_and_oracle(env, di
             h = h @ w.T + b
             if j < len(post) - 1:
                 h = np.maximum(h, 0)
-        allclose_scaled(N(outs[True][s, :48]), h, 1e-5)
+        assert_close_scaled(N(outs[True][s, :48]), h, 1e-5, "dense path vs oracle, sample %d" % s)
+        assert_close_scaled(N(outs[False][s, :48]), h, 1e-5, "fused kernels vs oracle, sample %d" % s)

@@ -1506,6 +1506,38 @@ def test_config5_wide_layer_properties(env):
     assert torch.equal(yb[4096:], ys1)
 
 
+def test_config5_wide_layer_no_grad_takes_the_three_plane_dense_path(env):
+    """The same configs[4] layer under torch.no_grad(): the fp32 parity mode then runs draw-once + bnn_dense_forward_x3 on
+    the 256 x 128 tile (k_dense_bf16<4, 8, 4, 1, 3> on three-plane operands) -- the launch bench.py's roofline_wide_f32 leg
+    times.  (1) rows from every kind of tile equal the oracle in double on the Philox draw of the recorded key at 1e-5 of the
+    output scale (the bf16x3 contraction has no 4096-long fp32 chain: the tighter bar holds), (2) linearity with the draw
+    frozen, (3) it agrees with the grad-mode (fused-kernel) result of the same key."""
+    from conftest import assert_close_scaled
+    from bayesianneuralnetworks_amd.nn import NormalLinear
+    from bayesianneuralnetworks_amd import ops
+    dev, lib = env["dev"], env["lib"]
+    assert ops.DENSE_X3_F32
+    torch.manual_seed(4)
+    layer = NormalLinear(4096, 4096, True).to(dev)
+    env["bnn"].manual_seed(21)
+    x1 = torch.randn(4096, 4096, device=dev)
+    x2 = torch.randn(4096, 4096, device=dev)
+    with torch.no_grad():
+        n0 = lib.bnn_launch_count()
+        y1 = layer(x1)
+        assert lib.bnn_launch_count() == n0 + 3, "draw + split of the input + one dense launch expected"
+        y2 = layer(x2, sample=False)
+        y12 = layer(0.5 * x1 - x2, sample=False)
+    b = layer.sampled[1]
+    assert_close_scaled(N(y12 - b), N(0.5 * (y1 - b) - (y2 - b)), 2e-5, "linearity")
+    w, bo = _oracle_layer_draw(env["orc"], layer, 0)
+    rows = torch.cat([torch.arange(r, r + 16) for r in (0, 240, 256, 1000, 2040, 2176, 3824, 4080)])
+    want = N(x1[rows.to(dev)]).astype(np.float64) @ w.astype(np.float64).T + bo.astype(np.float64)
+    assert_close_scaled(N(y1[rows.to(dev)]), want, 1e-5, "x3 dense path at 4096 vs oracle")
+    yg = layer(x1, sample=False)                       # grad mode: the fused kernel on the same key
+    assert_close_scaled(N(yg[rows.to(dev)]), want, 5e-5, "fused kernel at 4096 vs oracle")
+
+
 def test_config4_cifar_conv_mc_batched(env):
     """BASELINE configs[3] shape: NormalConv2d(128, 128, 3, padding=1) on (256, 128, 4, 4), 8 MC
     samples in one launch; sample s of the batched launch == oracle conv on a batch slice with the

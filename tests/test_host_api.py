@@ -404,3 +404,22 @@ def test_fuse_activations_marks_compute_format_hand_overs_and_x3_round_trip():
     assert act.shape == (6, 40) and act.dim() == 2 and not act.is_cuda
     back = act.float()
     assert back.shape == (6, 40) and (back - v).abs().max() <= v.abs().max() * 2.0 ** -23
+
+
+def test_rows_pitch_reads_the_strides_off_the_view():
+    """the dense path launches with the (row pitch, sample stride) rows_pitch validated, never with values
+    re-derived from M and K -- one padded row per sample (S, 1, K) sits stride(0) apart."""
+    from bayesianneuralnetworks_amd import ops
+    buf = torch.zeros(4, 1, 1216, dtype=torch.bfloat16)
+    v = buf[:, :, :1200]                                   # what _dense_raw(pad_rows=True) returns for M = 1
+    assert ops.rows_pitch(v, 1200) == (1200, 1216)
+    buf = torch.zeros(4, 16, 1216, dtype=torch.bfloat16)
+    assert ops.rows_pitch(buf[:, :, :1200], 1200) == (1216, 16 * 1216)
+    assert ops.rows_pitch(buf[0, :, :1200], 1200) == (1216, 16 * 1216)
+    assert ops.rows_pitch(buf[:, :8, :1200], 1200) == (1216, 16 * 1216)        # a row slice: samples still 16 rows apart
+    assert ops.rows_pitch(torch.zeros(2, 3, 64, dtype=torch.bfloat16), 64) == (64, 192)
+    assert ops.rows_pitch(torch.zeros(3, 64), 64) is None                                       # fp32
+    assert ops.rows_pitch(torch.zeros(3, 68, dtype=torch.bfloat16)[:, :64], 64) is None         # pitch not whole 16-B chunks
+    assert ops.rows_pitch(torch.zeros(8, 128, dtype=torch.bfloat16)[:, ::2], 64) is None        # element stride 2
+    assert ops.rows_pitch(torch.zeros(1, 64, dtype=torch.bfloat16).expand(4, 64).unsqueeze(1), 64) is None   # samples overlap (stride 0)
+    assert ops.rows_regular(buf[:, :, :1200], 1200) and not ops.rows_regular(torch.zeros(3, 64), 64)
