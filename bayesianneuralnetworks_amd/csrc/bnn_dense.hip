@@ -46,6 +46,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------------ (1) multi-tensor draw
 constexpr int kDrawMaxTensors = 8;
+constexpr int kDrawSpreadBelow = 4096;      // tensors of fewer 8-column groups: one thread per (group, sample)
 
 struct DrawTensorDev {
     const float *mu;
@@ -57,6 +58,7 @@ struct DrawTensorDev {
     int32_t kind;               // 0: draw mu + sigma eps; 1: mu as it is; 2: sigma = 1e-10 + softplus(rho) (Flipout's two operands)
     int32_t perm_taps;          // > 1: a conv weight (O, C, KH, KW) written tap-major: column c * taps + t -> t * (cols / taps) + c
     int32_t first_item;         // first work item (8-column group) of this tensor within the launch
+    int32_t spread;             // 1: a small tensor -- one thread per (8-column group, MC sample) instead of per group
     RngDev rng;
 };
 struct DrawLaunch {
@@ -69,6 +71,10 @@ struct DrawLaunch {
 };
 
 // One work item = 8 consecutive columns of one row = two Philox blocks; sigma once, then the S samples.
+// SMALL tensors (a bias, a classifier head: `spread`) take one thread per (item, sample) instead: a thread that draws its S
+// samples one after the other is a serial chain of ~1.2 us per sample when its wave has a SIMD to itself, and a launch is as
+// long as its longest wave -- the three 1-workgroup bias tensors of the BASELINE net were 8.7 of the launch's 29 us
+// (tools/draw_exp2.py: 20.5 us without them), although they are 0.1 % of the draws.
 // A tensor's items start at a multiple of 256 (first_item): a workgroup works on ONE tensor, whose descriptor is then
 // wave-uniform -- read once with scalar loads and kept in SGPRs.  (Indexed per thread, L.t[ti] was re-read from the
 // kernel-argument segment by vector loads inside the sample loop -- the stores may alias it as far as the compiler
@@ -99,8 +105,18 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     const int t_kind = L.t[ti].kind;
     const RngDev rng = L.t[ti].rng;
     const int S = L.nsamples;
-    const int local = item0 + (int)threadIdx.x - L.t[ti].first_item;
+    int local = item0 + (int)threadIdx.x - L.t[ti].first_item;
     const int gpr = (t_ld + 7) >> 3;                 // 8-column groups per output row
+    // the samples this thread draws: s_lo, s_lo + s_step, ... < s_hi
+    int s_lo = (int)blockIdx.y, s_hi = S, s_step = (int)gridDim.y;
+    if (L.t[ti].spread) {
+        if (blockIdx.y != 0) return;
+        const int nit = t_rows * gpr;
+        s_lo = local / nit;
+        local -= s_lo * nit;
+        s_hi = s_lo < S ? s_lo + 1 : 0;
+        s_step = 1;
+    }
     const int row = local / gpr, c0 = (local - row * gpr) << 3;
     if (row >= t_rows) return;
     const int64_t orow = (int64_t)row * t_ld + c0;
@@ -108,10 +124,55 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     char *const dst0 = t_out + orow * esz;
     const int64_t sbytes = t_stride * esz;
     const int64_t pbytes = sbytes * L.nsamples;     // (three-plane output)
+    // ---- the regular case, where the time goes: a weight matrix drawn as bf16 (or as three bf16 planes) whose rows are whole,
+    // 16-B aligned 8-column groups.  What decides the code path is wave-uniform (read off the tensor's descriptor), the sample
+    // loop is straight-line code, and the groups in the zero padding run the same loop with mean = sigma = 0 (a few % of wasted
+    // draws instead of a divergent second loop in almost every wave: a row end falls into most 64-item spans).
+    const bool regular = t_bf16 && t_kind == 0 && t_taps <= 1 && (t_cols & 7) == 0 &&
+                         (((reinterpret_cast<uintptr_t>(t_mu) | reinterpret_cast<uintptr_t>(t_rho)) & 15u) == 0);
+    if (regular) {
+        const bool pad = c0 >= t_cols;
+        const int64_t e0 = pad ? 0 : (int64_t)row * t_cols + c0;
+        const float4 m0 = *reinterpret_cast<const float4 *>(t_mu + e0), m1 = *reinterpret_cast<const float4 *>(t_mu + e0 + 4);
+        const float4 r0 = *reinterpret_cast<const float4 *>(t_rho + e0), r1 = *reinterpret_cast<const float4 *>(t_rho + e0 + 4);
+        const float live = pad ? 0.f : 1.f;          // (0 * finite = 0; a NaN parameter would show in its own row anyway)
+        const float m[8] = {pad ? 0.f : m0.x, pad ? 0.f : m0.y, pad ? 0.f : m0.z, pad ? 0.f : m0.w,
+                            pad ? 0.f : m1.x, pad ? 0.f : m1.y, pad ? 0.f : m1.z, pad ? 0.f : m1.w};
+        const float sg[8] = {live * sigma_draw(r0.x), live * sigma_draw(r0.y), live * sigma_draw(r0.z), live * sigma_draw(r0.w),
+                             live * sigma_draw(r1.x), live * sigma_draw(r1.y), live * sigma_draw(r1.z), live * sigma_draw(r1.w)};
+        const uint32_t edev = rng_epoch_dev(rng);
+        const PhiloxKeys keys = philox_keys(rng.key0, rng.key1);
+        const uint32_t blk = (uint32_t)(e0 >> 2);
+        char *dst = dst0 + (int64_t)s_lo * sbytes;
+        const int64_t step = sbytes * (int64_t)s_step;
+#pragma unroll U
+        for (int s = s_lo; s < s_hi; s += s_step, dst += step) {
+            const uint32_t sample = rng.sample0 + (uint32_t)s;
+            const float4 za = eps4(rng, keys, edev, blk, sample), zb = eps4(rng, keys, edev, blk + 1u, sample);
+            float w[8];
+            w[0] = fmaf(sg[0], za.x, m[0]); w[1] = fmaf(sg[1], za.y, m[1]);
+            w[2] = fmaf(sg[2], za.z, m[2]); w[3] = fmaf(sg[3], za.w, m[3]);
+            w[4] = fmaf(sg[4], zb.x, m[4]); w[5] = fmaf(sg[5], zb.y, m[5]);
+            w[6] = fmaf(sg[6], zb.z, m[6]); w[7] = fmaf(sg[7], zb.w, m[7]);
+            if (t_x3) {
+                uint4 h, mm, l;
+                split_bf16x3(w[0], w[1], h.x, mm.x, l.x); split_bf16x3(w[2], w[3], h.y, mm.y, l.y);
+                split_bf16x3(w[4], w[5], h.z, mm.z, l.z); split_bf16x3(w[6], w[7], h.w, mm.w, l.w);
+                *reinterpret_cast<uint4 *>(dst) = h;
+                *reinterpret_cast<uint4 *>(dst + pbytes) = mm;
+                *reinterpret_cast<uint4 *>(dst + 2 * pbytes) = l;
+            } else {
+                uint4 o;
+                o.x = pack_bf16x2(w[0], w[1]); o.y = pack_bf16x2(w[2], w[3]);
+                o.z = pack_bf16x2(w[4], w[5]); o.w = pack_bf16x2(w[6], w[7]);
+                *reinterpret_cast<uint4 *>(dst) = o;
+            }
+        }
+        return;
+    }
     if (c0 >= t_cols) {
         // padding columns: zeros (the dense kernel's K tail multiplies them with clamped, finite activations)
-        for (int s = 0; s < S; ++s) {
-            if (s % (int)gridDim.y != (int)blockIdx.y) continue;
+        for (int s = s_lo; s < s_hi; s += s_step) {
             if (t_bf16) {
                 for (int pl = 0; pl < (t_x3 ? 3 : 1); ++pl) *reinterpret_cast<uint4 *>(dst0 + s * sbytes + pl * pbytes) = make_uint4(0u, 0u, 0u, 0u);
             } else
@@ -151,7 +212,7 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     // gridDim.y > 1 (small launches: a conv weight is 18 workgroups): the samples are dealt over blockIdx.y as well -- sigma is
     // recomputed per slice, but a thread is no longer one long serial chain of S draws on a mostly idle chip
 #pragma unroll U
-    for (int s = (int)blockIdx.y; s < S; s += (int)gridDim.y) {
+    for (int s = s_lo; s < s_hi; s += s_step) {
         const uint32_t sample = rng.sample0 + (uint32_t)s;
         float4 za = make_float4(0.f, 0.f, 0.f, 0.f), zb = za;
         if (t_kind == 0) {
@@ -1057,7 +1118,9 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         if (t.taps > 1 && (t.cols % t.taps != 0 || t.out_dtype != BNN_BF16)) { set_error("%s: tensor %d: taps must divide cols (bf16 output)", who, i); return BNN_E_SHAPE; }
         d.first_item = (int32_t)items;
         d.rng = make_rng(&t.rng);
-        items += (t.rows * ((t.ld + 7) / 8) + 255) / 256 * 256;     // a workgroup works on one tensor
+        const int64_t nit = t.rows * ((t.ld + 7) / 8);
+        d.spread = (nit < kDrawSpreadBelow && nsamples > 1 && nit * nsamples <= 0x7FFFFFFF) ? 1 : 0;
+        items += ((d.spread ? nit * nsamples : nit) + 255) / 256 * 256;     // a workgroup works on one tensor
         if (items > 0x7FFFFF00) { set_error("%s: too many elements for one call", who); return BNN_E_RANGE; }
     }
     L.total_items = (int32_t)items;
@@ -1078,6 +1141,11 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
     // pipelined bench 156 / 153 / 143 k MC-samples/s with 1 / 2 / 4)
     static const int force_split = [] { const char *e = getenv("BNN_DRAW_SPLIT"); return e ? atoi(e) : 0; }();
     if (force_split >= 1 && force_split <= nsamples) split = force_split;
+    static const int unroll = [] { const char *e = getenv("BNN_DRAW_UNROLL"); return e ? atoi(e) : 1; }();
+    if (unroll == 2) hipLaunchKernelGGL(k_draw_multi<2>, dim3((unsigned)grid, (unsigned)split), dim3(256), 0, (hipStream_t)stream, L);
+    else if (unroll == 4) hipLaunchKernelGGL(k_draw_multi<4>, dim3((unsigned)grid, (unsigned)split), dim3(256), 0, (hipStream_t)stream, L);
+    else if (unroll == 8) hipLaunchKernelGGL(k_draw_multi<8>, dim3((unsigned)grid, (unsigned)split), dim3(256), 0, (hipStream_t)stream, L);
+    else
     hipLaunchKernelGGL(k_draw_multi<1>, dim3((unsigned)grid, (unsigned)split), dim3(256), 0, (hipStream_t)stream, L);
     return check_launch(who);
 }

@@ -89,6 +89,24 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, const PhiloxKeys &k)
     return c;
 }
 
+// R rounds of the same function (R = 7: Philox4x32-7, the fewest rounds Random123 lists as passing BigCrush)
+template <int R>
+__device__ __forceinline__ uint4 philox4x32_r(uint4 c, const PhiloxKeys &k)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        uint4 n;
+        n.x = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k.k0[r], 0x96);
+        n.y = (uint32_t)p1;
+        n.z = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k.k1[r], 0x96);
+        n.w = (uint32_t)p0;
+        c = n;
+    }
+    return c;
+}
+
 // Same function with the keys left in SGPRs (kernels that draw a handful of blocks: bias, tails).
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1)
 {
@@ -141,6 +159,16 @@ __device__ __forceinline__ float ln_unit(float u)
 __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float &z0, float &z1)
 {
     const float ua = u01(xa), ub = u01(xb);
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * ln_unit(ua));
+    z0 = r * __builtin_amdgcn_cosf(ub);
+    z1 = r * __builtin_amdgcn_sinf(ub);
+}
+
+// One Box-Muller pair from the two 16-bit halves of ONE random word: u = (h + 0.5) 2^-16 in (0, 1).
+__device__ __forceinline__ void box_muller16(uint32_t x, float &z0, float &z1)
+{
+    const float ua = __builtin_fmaf((float)(x & 0xFFFFu), 0x1p-16f, 0x1p-17f);
+    const float ub = __builtin_fmaf((float)(x >> 16), 0x1p-16f, 0x1p-17f);
     const float r = __builtin_amdgcn_sqrtf(-2.0f * ln_unit(ua));
     z0 = r * __builtin_amdgcn_cosf(ub);
     z1 = r * __builtin_amdgcn_sinf(ub);
