@@ -24,6 +24,9 @@ class BnnHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2            # include/bnn_hip.h BNN_ABI_VERSION
+
+
 class Rng(ctypes.Structure):
     """bnn_rng_t"""
     _fields_ = [("seed", ctypes.c_uint64),
@@ -31,7 +34,9 @@ class Rng(ctypes.Structure):
                 ("sample0", ctypes.c_uint32),
                 ("epoch_host", ctypes.c_uint32),
                 ("epoch_dev_delta", ctypes.c_int32),
-                ("epoch_dev", ctypes.c_void_p)]
+                ("epoch_dev", ctypes.c_void_p),
+                ("generator", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
 
 
 class KlTensor(ctypes.Structure):
@@ -160,6 +165,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.bnn_abi_version() != ABI_VERSION:
+        raise BnnHipError("libbnn_hip.so has ABI version %d, this package binds version %d (bnn_rng_t carries the generator id "
+                          "since version 2): rebuild with `make -C bayesianneuralnetworks_amd/csrc`" % (lib.bnn_abi_version(), ABI_VERSION))
     _lib = _DeviceGuarded(lib)
     return _lib
 

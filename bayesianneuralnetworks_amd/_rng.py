@@ -100,18 +100,39 @@ def manual_seed(seed):
     default_generator.manual_seed(seed)
 
 
-class DrawKey:
-    """Everything needed to re-create one draw of one tensor."""
-    __slots__ = ("seed", "stream", "sample0", "nsamples", "epoch_host", "epoch_dev_delta")
+GEN_PHILOX10_U24 = 0        # include/bnn_hip.h BNN_GEN_*: the default stream (24-bit uniforms, 4 eps per Philox4x32-10 block)
+GEN_PHILOX7_U16 = 1         # 8 eps per Philox4x32-7 block from 16-bit uniforms: for weights that are rounded to bf16 anyway
 
-    def __init__(self, seed, stream, sample0, nsamples, epoch_host, epoch_dev_delta=0):
+# which stream a layer's sample() keys its draw with in the bf16 compute mode (BNN_BF16_GENERATOR=philox10 keeps the default
+# stream everywhere, for A/B runs); the fp32 parity mode always draws from the default stream
+_bf16_gen = GEN_PHILOX10_U24 if __import__("os").environ.get("BNN_BF16_GENERATOR", "philox7") == "philox10" else GEN_PHILOX7_U16
+
+
+def generator_for(compute_mode):
+    return _bf16_gen if compute_mode == "bf16" else GEN_PHILOX10_U24
+
+
+def set_bf16_generator(name):
+    """'philox7' (default: BNN_GEN_PHILOX7_U16) or 'philox10' (the default stream) for draws keyed in the bf16 compute mode."""
+    global _bf16_gen
+    if name not in ("philox7", "philox10"):
+        raise ValueError("generator must be 'philox7' or 'philox10'")
+    _bf16_gen = GEN_PHILOX7_U16 if name == "philox7" else GEN_PHILOX10_U24
+
+
+class DrawKey:
+    """Everything needed to re-create one draw of one tensor (gen: which eps stream, part of the key)."""
+    __slots__ = ("seed", "stream", "sample0", "nsamples", "epoch_host", "epoch_dev_delta", "gen")
+
+    def __init__(self, seed, stream, sample0, nsamples, epoch_host, epoch_dev_delta=0, gen=GEN_PHILOX10_U24):
         self.seed = seed
         self.stream = stream
         self.sample0 = sample0
         self.nsamples = nsamples
         self.epoch_host = epoch_host
         self.epoch_dev_delta = epoch_dev_delta
+        self.gen = gen
 
     def last_sample(self):
         return DrawKey(self.seed, self.stream, self.sample0 + self.nsamples - 1, 1,
-                       self.epoch_host, self.epoch_dev_delta)
+                       self.epoch_host, self.epoch_dev_delta, self.gen)

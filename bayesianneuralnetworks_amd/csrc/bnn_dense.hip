@@ -66,7 +66,7 @@ struct DrawLaunch {
     int32_t ntensors;
     int32_t nsamples;
     int32_t total_items;
-    int32_t draw_blocks;        // workgroups >= draw_blocks run the KL's first pass
+    int32_t draw_blocks;        // workgroups of the draw (the first L.kl.nblocks workgroups of the grid run the KL's first pass)
     KlPiggy kl;
 };
 
@@ -83,11 +83,14 @@ struct DrawLaunch {
 template <int U>
 __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
 {
-    if ((int)blockIdx.x >= L.draw_blocks) {
-        if (blockIdx.y == 0) kl_piggy_block(L.kl, (int)blockIdx.x - L.draw_blocks);
+    // The KL's workgroups come FIRST in the grid: they are short (8 or 16 scalars per thread, no sample loop) and the dispatcher
+    // hands workgroups out in index order -- at the end of the grid they waited for a draw workgroup to retire and became the
+    // launch's tail (BASELINE launch, 16-bit stream: 20.0 us; in front: see DESIGN).
+    if ((int)blockIdx.x < L.kl.nblocks) {
+        if (blockIdx.y == 0) kl_piggy_block(L.kl, (int)blockIdx.x);
         return;
     }
-    const int item0 = (int)blockIdx.x * 256;
+    const int item0 = ((int)blockIdx.x - L.kl.nblocks) * 256;
     int ti = 0;
 #pragma unroll
     for (int i = 1; i < kDrawMaxTensors; ++i)
@@ -145,10 +148,17 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
         const uint32_t blk = (uint32_t)(e0 >> 2);
         char *dst = dst0 + (int64_t)s_lo * sbytes;
         const int64_t step = sbytes * (int64_t)s_step;
+        const bool gen16 = rng.gen == BNN_GEN_PHILOX7_U16;      // (wave-uniform)
 #pragma unroll U
         for (int s = s_lo; s < s_hi; s += s_step, dst += step) {
             const uint32_t sample = rng.sample0 + (uint32_t)s;
-            const float4 za = eps4(rng, keys, edev, blk, sample), zb = eps4(rng, keys, edev, blk + 1u, sample);
+            float4 za, zb;
+            if (gen16) {
+                eps8_u16(rng, keys, edev, blk >> 1, sample, za, zb);    // the item IS one 8-eps block (e0 % 8 == 0)
+            } else {
+                za = eps4(rng, keys, edev, blk, sample);
+                zb = eps4(rng, keys, edev, blk + 1u, sample);
+            }
             float w[8];
             w[0] = fmaf(sg[0], za.x, m[0]); w[1] = fmaf(sg[1], za.y, m[1]);
             w[2] = fmaf(sg[2], za.z, m[2]); w[3] = fmaf(sg[3], za.w, m[3]);

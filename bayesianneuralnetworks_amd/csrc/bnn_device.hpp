@@ -22,6 +22,7 @@ struct RngDev {
     uint32_t epoch_host;
     int32_t epoch_dev_delta;
     const uint32_t *epoch_dev;
+    uint32_t gen;              // BNN_GEN_*
 };
 
 static inline RngDev make_rng(const bnn_rng_t *r)
@@ -35,6 +36,7 @@ static inline RngDev make_rng(const bnn_rng_t *r)
         d.epoch_host = r->epoch_host;
         d.epoch_dev_delta = r->epoch_dev_delta;
         d.epoch_dev = r->epoch_dev;
+        d.gen = r->generator;
     }
     return d;
 }
@@ -44,6 +46,7 @@ static inline int check_rng(const bnn_rng_t *r, int nsamples)
     if (!r) return BNN_E_NULL;
     if (r->stream > 0xFFFFu) return BNN_E_RANGE;
     if ((uint64_t)r->sample0 + (uint64_t)nsamples > 0x10000ull) return BNN_E_RANGE;
+    if (r->generator > BNN_GEN_PHILOX7_U16) return BNN_E_RANGE;
     return BNN_OK;
 }
 
@@ -89,7 +92,7 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, const PhiloxKeys &k)
     return c;
 }
 
-// R rounds of the same function (R = 7: Philox4x32-7, the fewest rounds Random123 lists as passing BigCrush)
+// R rounds of the same function (R = 7: Philox4x32-7, the 7-round member Random123 ships known answers for)
 template <int R>
 __device__ __forceinline__ uint4 philox4x32_r(uint4 c, const PhiloxKeys &k)
 {
@@ -112,6 +115,25 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint32_t k0, uint32_t k1
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        uint4 n;
+        n.x = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k0, 0x96);
+        n.y = (uint32_t)p1;
+        n.z = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k1, 0x96);
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+template <int R>
+__device__ __forceinline__ uint4 philox4x32_r(uint4 c, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
         uint4 n;
@@ -174,13 +196,31 @@ __device__ __forceinline__ void box_muller16(uint32_t x, float &z0, float &z1)
     z1 = r * __builtin_amdgcn_sinf(ub);
 }
 
-// The four eps values of Philox block `block` (elements 4*block .. 4*block+3).
+// BNN_GEN_PHILOX7_U16: the EIGHT eps values of block `block8` (elements 8 block8 .. 8 block8 + 7), keys in VGPRs
+__device__ __forceinline__ void eps8_u16(const RngDev &r, const PhiloxKeys &keys, uint32_t epoch_dev, uint32_t block8,
+                                         uint32_t sample, float4 &za, float4 &zb)
+{
+    const uint4 x = philox4x32_r<7>(make_uint4(block8, r.stream_hi | (sample & 0xFFFFu), r.epoch_host, epoch_dev), keys);
+    box_muller16(x.x, za.x, za.y); box_muller16(x.y, za.z, za.w);
+    box_muller16(x.z, zb.x, zb.y); box_muller16(x.w, zb.z, zb.w);
+}
+
+// The four eps values of quad `block` (elements 4*block .. 4*block+3) of the stream r.gen names (wave-uniform branch).
+// BNN_GEN_PHILOX7_U16: the quad is one half of Philox block `block >> 1` (a caller that walks quads pays one 7-round block per
+// quad; the draw launch, where the time goes, takes whole blocks: eps8_u16).
 __device__ __forceinline__ float4 eps4(const RngDev &r, uint32_t epoch_dev, uint32_t block,
                                        uint32_t sample)
 {
+    float4 z;
+    if (r.gen == BNN_GEN_PHILOX7_U16) {
+        const uint4 x = philox4x32_r<7>(make_uint4(block >> 1, r.stream_hi | (sample & 0xFFFFu), r.epoch_host, epoch_dev), r.key0, r.key1);
+        const bool hi = (block & 1u) != 0;
+        box_muller16(hi ? x.z : x.x, z.x, z.y);
+        box_muller16(hi ? x.w : x.y, z.z, z.w);
+        return z;
+    }
     const uint4 x = philox4x32_10(make_uint4(block, r.stream_hi | (sample & 0xFFFFu),
                                              r.epoch_host, epoch_dev), r.key0, r.key1);
-    float4 z;
     box_muller(x.x, x.y, z.x, z.y);
     box_muller(x.z, x.w, z.z, z.w);
     return z;
@@ -190,9 +230,16 @@ __device__ __forceinline__ float4 eps4(const RngDev &r, uint32_t epoch_dev, uint
 __device__ __forceinline__ float4 eps4(const RngDev &r, const PhiloxKeys &keys, uint32_t epoch_dev, uint32_t block,
                                        uint32_t sample)
 {
+    float4 z;
+    if (r.gen == BNN_GEN_PHILOX7_U16) {
+        const uint4 x = philox4x32_r<7>(make_uint4(block >> 1, r.stream_hi | (sample & 0xFFFFu), r.epoch_host, epoch_dev), keys);
+        const bool hi = (block & 1u) != 0;
+        box_muller16(hi ? x.z : x.x, z.x, z.y);
+        box_muller16(hi ? x.w : x.y, z.z, z.w);
+        return z;
+    }
     const uint4 x = philox4x32_10(make_uint4(block, r.stream_hi | (sample & 0xFFFFu),
                                              r.epoch_host, epoch_dev), keys);
-    float4 z;
     box_muller(x.x, x.y, z.x, z.y);
     box_muller(x.z, x.w, z.z, z.w);
     return z;

@@ -57,14 +57,14 @@ class WeightNormal(Module):
         return self.mean.size(*dims)
 
     # ---- draws
-    def sample(self, nsamples=1, sample0=0, epoch=None):
+    def sample(self, nsamples=1, sample0=0, epoch=None, gen=0):
         """core.py:44-45.  CUDA/HIP: record the draw key (nothing is computed until a kernel
         needs the weights).  CPU tensors: the reference's own expression on torch's global
         generator -- host-side semantics for construction and CPU-resident modules."""
         if self.mean.is_cuda:
             if epoch is None:
                 epoch = default_generator.next_epoch()
-            self._key = DrawKey(default_generator.seed, self._stream, sample0, nsamples, epoch)
+            self._key = DrawKey(default_generator.seed, self._stream, sample0, nsamples, epoch, gen=gen)    # gen: _rng.GEN_*
             self._explicit = None
         else:
             self._key = None

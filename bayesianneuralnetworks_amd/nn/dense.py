@@ -17,7 +17,7 @@ from torch.distributions import Normal
 from torch.distributions.multivariate_normal import MultivariateNormal
 
 from .. import _mc, ops
-from .._rng import default_generator
+from .._rng import default_generator, generator_for
 from . import _settings
 from .container import BayesianModule
 from .core import WeightNormal, WeightMultivariateNormal
@@ -60,17 +60,19 @@ class _NormalSampling:
     def sample(self, nsamples=1, sample0=0):
         # weight first, then bias (dense.py:47-51); one epoch for the layer's draw
         epoch = default_generator.next_epoch() if self.weight.mean.is_cuda else None
-        self.weight.sample(nsamples, sample0, epoch)
+        gen = generator_for(self._compute_mode())       # the eps stream is part of the key: whoever re-creates the draw reads it there
+        self.weight.sample(nsamples, sample0, epoch, gen)
         if self.bias is not None:
-            self.bias.sample(nsamples, sample0, epoch)
+            self.bias.sample(nsamples, sample0, epoch, gen)
 
     def _fresh_keys(self, nsamples, sample0):
         """The DrawKeys sample(nsamples, sample0) would record, without recording them (the network's draw plan draws on
         them ahead of the layer's call; _adopt_keys records them when the layer uses that draw)."""
         from .._rng import DrawKey
         epoch = default_generator.next_epoch()
-        kw = DrawKey(default_generator.seed, self.weight._stream, sample0, nsamples, epoch)
-        kb = DrawKey(default_generator.seed, self.bias._stream, sample0, nsamples, epoch) if self.bias is not None else None
+        gen = generator_for(self._compute_mode())
+        kw = DrawKey(default_generator.seed, self.weight._stream, sample0, nsamples, epoch, gen=gen)
+        kb = DrawKey(default_generator.seed, self.bias._stream, sample0, nsamples, epoch, gen=gen) if self.bias is not None else None
         return kw, kb
 
     def _adopt_keys(self, kw, kb):

@@ -27,6 +27,7 @@ def _rng_struct(key, device):
     r.epoch_host = key.epoch_host
     r.epoch_dev_delta = key.epoch_dev_delta
     r.epoch_dev = default_generator.epoch_dev(device).data_ptr()
+    r.generator = key.gen
     return r
 
 

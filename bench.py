@@ -334,8 +334,8 @@ def oracle_check(step, post, x_cpu, mode, rows=64, tap=None, replay=True):
     for s in range(S):
         h = h0
         for li, ((mw, rw, mb, rb), (kw, kb)) in enumerate(zip(post, step.keys)):
-            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, e_dev + kw.epoch_dev_delta, tuple(mw.shape))
-            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, e_dev + kb.epoch_dev_delta, tuple(mb.shape))
+            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, e_dev + kw.epoch_dev_delta, tuple(mw.shape), kw.gen)
+            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, e_dev + kb.epoch_dev_delta, tuple(mb.shape), kb.gen)
             w = rnd(orc.sample_affine(mw.numpy(), rw.numpy(), ew))
             b = orc.sample_affine(mb.numpy(), rb.numpy(), eb)
             h = orc.linear(h, w, b)
@@ -496,7 +496,7 @@ def kernel_roofline(net, x, mode, dev):
     `roofline_draw`); fp32 mode: the fused sampled kernel.  Average launch duration from events on the launch stream
     around graph replays of 10 launches; algorithmic FLOPs."""
     from bayesianneuralnetworks_amd import _mc, ops
-    from bayesianneuralnetworks_amd._rng import DrawKey
+    from bayesianneuralnetworks_amd._rng import DrawKey, generator_for
     layer = net.layers[2]
     h = torch.randn(SAMPLES * BATCH, DIMS[1], device=dev).relu_()
     flops = 2.0 * SAMPLES * BATCH * DIMS[1] * DIMS[2]
@@ -510,7 +510,8 @@ def kernel_roofline(net, x, mode, dev):
         hb = torch.zeros(SAMPLES, BATCH, (DIMS[1] + 63) // 64 * 64, dtype=torch.bfloat16, device=dev)
         hb[:, :, :DIMS[1]] = h.view(SAMPLES, BATCH, -1)
         hv = hb[:, :, :DIMS[1]]
-        kw, kb = DrawKey(1, 1, 0, SAMPLES, 0), DrawKey(1, 2, 0, SAMPLES, 0)
+        g = generator_for("bf16")                   # the stream the bf16 mode keys its draws with (BNN_GEN_PHILOX7_U16)
+        kw, kb = DrawKey(1, 1, 0, SAMPLES, 0, gen=g), DrawKey(1, 2, 0, SAMPLES, 0, gen=g)
         spec = (layer.weight.mean.detach(), layer.weight.scale.detach(), layer.bias.mean.detach(), layer.bias.scale.detach(), kw, kb)
         pre = ops.draw_layers([spec], SAMPLES)[0]
         ld = hb.shape[2]
@@ -552,11 +553,12 @@ def draw_roofline(net, dev):
     not HBM-bound: one Philox4x32-10 block + two Box-Muller pairs are ~74 VALU instructions per 4 weights, of which the
     20 v_mad_u64_u32 and the 8 transcendentals issue at quarter rate: ~21 us of VALU issue on 1024 SIMDs."""
     from bayesianneuralnetworks_amd import ops
-    from bayesianneuralnetworks_amd._rng import DrawKey
+    from bayesianneuralnetworks_amd._rng import DrawKey, generator_for
+    g = generator_for("bf16")
     specs = []
     for i, L in enumerate(m for m in net.layers if hasattr(m, "weight")):
         specs.append((L.weight.mean.detach(), L.weight.scale.detach(), L.bias.mean.detach(), L.bias.scale.detach(),
-                      DrawKey(1, 2 * i + 1, 0, SAMPLES, 0), DrawKey(1, 2 * i + 2, 0, SAMPLES, 0)))
+                      DrawKey(1, 2 * i + 1, 0, SAMPLES, 0, gen=g), DrawKey(1, 2 * i + 2, 0, SAMPLES, 0, gen=g)))
     us = _graph_time(lambda: ops.draw_layers(specs, SAMPLES), dev)
     nbytes = 8.0 * P_SCALARS + 2.0 * SAMPLES * P_SCALARS
     gbs = nbytes / us / 1e3

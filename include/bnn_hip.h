@@ -28,6 +28,17 @@
  *   that a replayed graph draws fresh noise: bnn_rng_advance bumps it in-stream.
  *   The draw depends only on (seed, stream, sample, epochs, e): not on tiling,
  *   grid size, or the number of GPUs the MC samples are sharded over.
+ *
+ *   rng->generator selects the eps source (part of the key: every kernel that re-creates a draw -- the draw launch, the
+ *   fused GEMM, the standalone sampler, the backward -- reads it from the same struct, so a draw is the same everywhere):
+ *     BNN_GEN_PHILOX10_U24 (0, default): the stream above -- 24-bit uniforms, four eps per Philox4x32-10 block.
+ *     BNN_GEN_PHILOX7_U16  (1): EIGHT eps per Philox4x32-7 block, from 16-bit uniforms -- for weights that are rounded to
+ *       bf16 (8 significand bits) anyway; 0.4 x the integer work per eps (the draw launch of the BASELINE net: 16.5 -> 13.3 us):
+ *         (x0..x3) = Philox4x32-7(counter = (e / 8, (stream << 16) | sample, epoch_host, epoch_dev), key as above)
+ *         word x_k feeds elements 8 (e / 8) + 2 k and + 2 k + 1:  ua = ((x_k & 0xffff) + 0.5) 2^-16,  ub = ((x_k >> 16) + 0.5) 2^-16,
+ *         z_even = r(ua) cos(2 pi ub), z_odd = r(ua) sin(2 pi ub);  |eps| <= r(2^-17) = 4.86.
+ *       Philox4x32-7 is the 7-round member of the same family (Random123's kat_vectors hold its known answers, checked in
+ *       tests/test_oracle_golden.py); CPU twin: orc_eps_fill_gen.
  */
 #ifndef BNN_HIP_H
 #define BNN_HIP_H
@@ -38,7 +49,7 @@
 extern "C" {
 #endif
 
-#define BNN_ABI_VERSION 1
+#define BNN_ABI_VERSION 2
 
 enum {
     BNN_OK = 0,
@@ -65,6 +76,8 @@ enum {
     BNN_COMPUTE_BF16 = 1  /* operands rounded to bf16 (RNE), v_mfma_f32_16x16x32_bf16, fp32 accumulate */
 };
 
+enum { BNN_GEN_PHILOX10_U24 = 0, BNN_GEN_PHILOX7_U16 = 1 };
+
 /* One eps stream (host struct, read at call time). */
 typedef struct bnn_rng {
     uint64_t seed;
@@ -73,6 +86,8 @@ typedef struct bnn_rng {
     uint32_t epoch_host;        /* host-side draw counter */
     int32_t epoch_dev_delta;    /* added to *epoch_dev (e.g. -1 to re-create the previous replay's draw) */
     const uint32_t *epoch_dev;  /* device word bumped by bnn_rng_advance; NULL = 0 */
+    uint32_t generator;         /* BNN_GEN_* (RNG contract above) */
+    uint32_t reserved;          /* 0 */
 } bnn_rng_t;
 
 /* One Gaussian posterior tensor with its Gaussian prior (host struct). */

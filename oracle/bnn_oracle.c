@@ -221,6 +221,64 @@ void orc_eps4(uint64_t seed, uint32_t block, uint32_t stream, uint32_t sample,
     }
 }
 
+/* R rounds of the same function: R = 7 is Philox4x32-7 (known answers in Random123's kat_vectors). */
+void orc_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < rounds; ++r) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* BNN_GEN_PHILOX7_U16 (include/bnn_hip.h, "RNG contract"): EIGHT eps per Philox4x32-7 block,
+ *   counter = (element_index / 8, (stream << 16) | sample, epoch_host, epoch_dev),
+ *   word x_k -> elements 2 k, 2 k + 1 of the block: ua = ((x_k & 0xffff) + 0.5) 2^-16, ub = ((x_k >> 16) + 0.5) 2^-16,
+ *   z_even = r cos t, z_odd = r sin t, r = sqrt(-2 ln ua), t = 2 pi ub.  Evaluated in double, rounded once. */
+void orc_eps8_u16(uint64_t seed, uint32_t block8, uint32_t stream, uint32_t sample,
+                  uint32_t epoch_host, uint32_t epoch_dev, float z[8])
+{
+    uint32_t ctr[4] = { block8, (stream << 16) | (sample & 0xFFFFu), epoch_host, epoch_dev };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    uint32_t x[4];
+    orc_philox4x32_r(ctr, key, 7, x);
+    for (int k = 0; k < 4; ++k) {
+        double ua = ((double)(x[k] & 0xFFFFu) + 0.5) / 65536.0;
+        double ub = ((double)(x[k] >> 16) + 0.5) / 65536.0;
+        double r = sqrt(-2.0 * log(ua));
+        double t = 6.283185307179586476925286766559 * ub;
+        z[2 * k] = (float)(r * cos(t));
+        z[2 * k + 1] = (float)(r * sin(t));
+    }
+}
+
+/* eps of the stream `gen` names: 0 = BNN_GEN_PHILOX10_U24 (orc_eps4), 1 = BNN_GEN_PHILOX7_U16 (orc_eps8_u16). */
+void orc_eps_fill_gen(uint64_t seed, uint32_t stream, uint32_t sample,
+                      uint32_t epoch_host, uint32_t epoch_dev, int gen, int64_t n, float *eps)
+{
+    if (gen == 0) {
+        for (int64_t b = 0; b * 4 < n; ++b) {
+            float z[4];
+            orc_eps4(seed, (uint32_t)b, stream, sample, epoch_host, epoch_dev, z);
+            for (int j = 0; j < 4 && b * 4 + j < n; ++j) eps[b * 4 + j] = z[j];
+        }
+        return;
+    }
+    for (int64_t b = 0; b * 8 < n; ++b) {
+        float z[8];
+        orc_eps8_u16(seed, (uint32_t)b, stream, sample, epoch_host, epoch_dev, z);
+        for (int j = 0; j < 8 && b * 8 + j < n; ++j) eps[b * 8 + j] = z[j];
+    }
+}
+
 void orc_eps_fill(uint64_t seed, uint32_t stream, uint32_t sample,
                   uint32_t epoch_host, uint32_t epoch_dev, int64_t n, float *eps)
 {

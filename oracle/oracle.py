@@ -50,6 +50,9 @@ def lib():
         L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
         L.orc_eps_fill.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                    ctypes.c_uint32, ctypes.c_uint32, _i64, _f32p]
+        L.orc_philox4x32_r.argtypes = [_u32p, _u32p, ctypes.c_int, _u32p]
+        L.orc_eps_fill_gen.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, _i64, _f32p]
         L.orc_bf16_round.argtypes = [ctypes.c_float]
         L.orc_bf16_round.restype = ctypes.c_float
         _lib = L
@@ -205,14 +208,30 @@ def philox4x32_10(ctr, key):
     return out
 
 
-def eps_fill(seed, stream, sample, epoch_host, epoch_dev, shape):
-    """orc_eps_fill -- the build's own Philox/Box-Muller eps stream (RNG contract
-    in include/bnn_hip.h)."""
+def philox4x32_r(ctr, key, rounds):
+    """orc_philox4x32_r -- `rounds` rounds of the Philox4x32 round function (7: Philox4x32-7)."""
+    c = np.ascontiguousarray(ctr, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(4, dtype=np.uint32)
+    lib().orc_philox4x32_r(c.ctypes.data_as(_u32p), k.ctypes.data_as(_u32p), int(rounds), out.ctypes.data_as(_u32p))
+    return out
+
+
+def eps_fill(seed, stream, sample, epoch_host, epoch_dev, shape, gen=0):
+    """orc_eps_fill_gen -- the build's own Philox/Box-Muller eps stream (RNG contract in include/bnn_hip.h);
+    gen: 0 = BNN_GEN_PHILOX10_U24 (the default stream), 1 = BNN_GEN_PHILOX7_U16 (a DrawKey's .gen)."""
     n = int(np.prod(shape))
     out = np.empty(n, dtype=np.float32)
-    lib().orc_eps_fill(int(seed) & (2**64 - 1), stream, sample, epoch_host, epoch_dev, n,
-                       out.ctypes.data_as(_f32p))
+    lib().orc_eps_fill_gen(int(seed) & (2**64 - 1), stream, sample & 0xFFFFFFFF, epoch_host, epoch_dev & 0xFFFFFFFF, int(gen), n,
+                           out.ctypes.data_as(_f32p))
     return out.reshape(shape)
+
+
+def eps_for_key(key, s, epoch_dev, shape):
+    """eps of MC sample `s` of the draw a DrawKey (seed, stream, sample0, epoch_host, epoch_dev_delta, gen) names, with the
+    device epoch word at `epoch_dev`."""
+    return eps_fill(key.seed, key.stream, key.sample0 + s, key.epoch_host, epoch_dev + key.epoch_dev_delta, shape,
+                    getattr(key, "gen", 0))
 
 
 def bf16_round(a):

@@ -35,13 +35,15 @@ def _post(shape, seed, dev, bias=True):
     return [t.to(dev) if t is not None else None for t in (mw, rw, mb, rb)]
 
 
-@pytest.mark.parametrize("shape", [(1200, 784), (10, 1200), (64, 48), (7, 16), (80, 264)])
+@pytest.mark.parametrize("gen", [0, 1])
+@pytest.mark.parametrize("shape", [(1200, 784), (10, 1200), (64, 48), (7, 16), (80, 264), (600, 1208)])
 @pytest.mark.parametrize("S", [1, 8])
-def test_draw_multi_equals_standalone_sampler_and_oracle(env, shape, S):
+def test_draw_multi_equals_standalone_sampler_and_oracle(env, shape, S, gen):
+    """(600 x 1208: 4530 groups -- past the small-tensor threshold, the one-thread-per-group path with a ragged row end.)"""
     from bayesianneuralnetworks_amd._rng import DrawKey
     ops, orc, dev = env["ops"], env["orc"], env["dev"]
     mw, rw, mb, rb = _post(shape, 5, dev)
-    kw, kb = DrawKey(99, 11, 2, S, 7), DrawKey(99, 12, 2, S, 7)
+    kw, kb = DrawKey(99, 11, 2, S, 7, gen=gen), DrawKey(99, 12, 2, S, 7, gen=gen)
     n0 = env["lib"].bnn_launch_count()
     pre = ops.draw_layers([(mw, rw, mb, rb, kw, kb)], S)[0]
     assert env["lib"].bnn_launch_count() == n0 + 1            # weight AND bias, all samples: one launch
@@ -55,11 +57,11 @@ def test_draw_multi_equals_standalone_sampler_and_oracle(env, shape, S):
     assert torch.equal(pre.b, ops._sample_affine_philox_raw(mb, rb, kb))
     # (b) the oracle's draw, rounded to bf16: at most one bf16 ulp apart (the eps twin agrees to ~1e-6)
     for s in range(S):
-        ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, shape)
+        ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, shape, kw.gen)
         want = orc.sample_affine(N(mw), N(rw), ew)
         got = N(pre.w[s, :, :K])
         assert (np.abs(got - want) <= np.abs(want) * 2.0 ** -8 + 1e-6).all()
-        eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, (Nn,))
+        eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, (Nn,), kb.gen)
         assert np.allclose(N(pre.b[s]), orc.sample_affine(N(mb), N(rb), eb), atol=1e-5, rtol=1e-5)
 
 
@@ -213,8 +215,8 @@ def test_layer_on_draw_once_path_equals_fused_kernel_and_oracle(env, dims, B, S)
     for s in range(S):
         h = h0
         for li, ((mw, rw, mb, rb), (kw, kb)) in enumerate(zip(posts, keys)):
-            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, tuple(mw.shape))
-            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, tuple(mb.shape))
+            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, tuple(mw.shape), kw.gen)
+            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, tuple(mb.shape), kb.gen)
             h = orc.linear(h, orc.bf16_round(orc.sample_affine(mw.numpy(), rw.numpy(), ew)), orc.sample_affine(mb.numpy(), rb.numpy(), eb))
             if li < len(posts) - 1:
                 h = orc.bf16_round(np.maximum(h, 0))
@@ -308,7 +310,7 @@ def test_conv_dense_path_vs_oracle(env, B, C, O, H, W, k, st, pad, dil, shared):
     assert torch.equal(wt, w1) and (pre.w[:, :, K:] == 0).all()
     # ... and within one bf16 ulp of the oracle's draw (a weight within the eps twin's 1e-6 of a rounding boundary rounds the
     # other way on one side, which is why the contraction below is checked on the DEVICE's weights)
-    ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0, kw.epoch_host, 0, tuple(layer.weight.shape))
+    ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0, kw.epoch_host, 0, tuple(layer.weight.shape), kw.gen)
     w_or = orc.sample_affine(N(layer.weight.mean), N(layer.weight.scale), ew)
     assert (np.abs(N(wt[0]) - w_or) <= np.abs(w_or) * 2.0 ** -8 + 1e-6).all()
     nb = min(B, 6)                                              # images checked per sample (first and last ones)

@@ -216,8 +216,8 @@ def test_fp32_mode_network_on_dense_path_equals_fused_kernels_and_oracle(env, di
         h = xs.astype(np.float64)
         for j, (mw, rw, mb, rb) in enumerate(post):
             kw, kb = keys[j]
-            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, tuple(mw.shape))
-            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, tuple(mb.shape))
+            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, 0, tuple(mw.shape), kw.gen)
+            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, 0, tuple(mb.shape), kb.gen)
             w = orc.sample_affine(mw.numpy(), rw.numpy(), ew).astype(np.float64)
             b = orc.sample_affine(mb.numpy(), rb.numpy(), eb).astype(np.float64)
             h = h @ w.T + b

@@ -43,27 +43,29 @@ CONV = ["conv_1_1_k1", "conv_3_4_k3_p1", "conv_4_6_k3_s2_d2_g2", "conv_mnist_pre
 # ------------------------------------------------------------------ library / RNG
 def test_library_identity_and_counter(env):
     lib = env["lib"]
-    assert lib.bnn_abi_version() == 1
+    assert lib.bnn_abi_version() == 2
     assert lib.bnn_arch() == b"gfx950"
     n0 = lib.bnn_launch_count()
     env["ops"].sigma(torch.zeros(8, device=env["dev"]))
     assert lib.bnn_launch_count() == n0 + 1
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 4096, 100003])
-def test_eps_stream_matches_cpu_twin(env, n):
+@pytest.mark.parametrize("gen", [0, 1])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 7, 8, 9, 1023, 4096, 100003])
+def test_eps_stream_matches_cpu_twin(env, n, gen):
     from bayesianneuralnetworks_amd._rng import DrawKey
-    key = DrawKey(0x1234567890ABCDEF, 777, 3, 4, 42)
+    key = DrawKey(0x1234567890ABCDEF, 777, 3, 4, 42, gen=gen)
     got = N(env["ops"].eps_philox((n,), key, env["dev"]))
     for s in range(4):
-        want = env["orc"].eps_fill(key.seed, key.stream, key.sample0 + s, key.epoch_host, 0, (n,))
+        want = env["orc"].eps_fill(key.seed, key.stream, key.sample0 + s, key.epoch_host, 0, (n,), key.gen)
         # eps itself: native sin/cos/sqrt on the GPU vs double on the CPU
         assert np.abs(got[s] - want).max() < 2e-5, np.abs(got[s] - want).max()
 
 
-def test_eps_stream_moments_and_independence(env):
+@pytest.mark.parametrize("gen", [0, 1])
+def test_eps_stream_moments_and_independence(env, gen):
     from bayesianneuralnetworks_amd._rng import DrawKey
-    e = N(env["ops"].eps_philox((1 << 20,), DrawKey(99, 5, 0, 2, 0), env["dev"]))
+    e = N(env["ops"].eps_philox((1 << 20,), DrawKey(99, 5, 0, 2, 0, gen=gen), env["dev"]))
     for s in range(2):
         assert abs(e[s].mean()) < 5e-3 and abs(e[s].std() - 1) < 5e-3
         assert abs((e[s] ** 4).mean() - 3) < 5e-2
@@ -109,17 +111,18 @@ def test_sigma_and_sample_affine_golden(env):
     assert allclose(w, g["w"])
 
 
+@pytest.mark.parametrize("rgen", [0, 1])
 @pytest.mark.parametrize("shape", [(1,), (3, 4), (5, 6, 7), (1200, 784), (10,), (64, 64, 3, 3)])
-def test_sample_affine_philox_vs_oracle(env, shape):
+def test_sample_affine_philox_vs_oracle(env, shape, rgen):
     from bayesianneuralnetworks_amd._rng import DrawKey
     dev = env["dev"]
     gen = torch.Generator().manual_seed(3)
     mu = torch.randn(shape, generator=gen) * 0.1
     rho = torch.randn(shape, generator=gen) * 0.15 - 2.0
-    key = DrawKey(2024, 11, 1, 3, 9)
+    key = DrawKey(2024, 11, 1, 3, 9, gen=rgen)
     got = N(env["ops"].sample_affine_philox(mu.to(dev), rho.to(dev), key))
     for s in range(3):
-        eps = env["orc"].eps_fill(key.seed, key.stream, key.sample0 + s, key.epoch_host, 0, shape)
+        eps = env["orc"].eps_fill(key.seed, key.stream, key.sample0 + s, key.epoch_host, 0, shape, key.gen)
         assert allclose(got[s], env["orc"].sample_affine(mu.numpy(), rho.numpy(), eps))
 
 
@@ -440,12 +443,12 @@ def test_linear_backward_golden(env, name):
 
 def _oracle_layer_draw(orc, layer, s, epoch_dev=0):
     kw = layer.weight.draw_key
-    ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, epoch_dev, tuple(layer.weight.shape))
+    ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, epoch_dev, tuple(layer.weight.shape), kw.gen)
     w = orc.sample_affine(N(layer.weight.mean), N(layer.weight.scale), ew)
     b = None
     if layer.bias is not None:
         kb = layer.bias.draw_key
-        eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, epoch_dev, tuple(layer.bias.shape))
+        eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, epoch_dev, tuple(layer.bias.shape), kb.gen)
         b = orc.sample_affine(N(layer.bias.mean), N(layer.bias.scale), eb)
     return w, b
 
@@ -735,12 +738,12 @@ def test_training_step_gradients_match_oracle(env):
         gw0 = gh0.T @ N(x)
         for (gw, L, gm, gr) in ((gw0, L0, g_mu0, g_rho0), (gw1, L1, g_mu1, g_rho1)):
             kw = L.weight.draw_key
-            ew = orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, 0, tuple(L.weight.shape))
+            ew = orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, 0, tuple(L.weight.shape), kw.gen)
             a, b_ = orc.sample_affine_bwd(gw.astype(np.float32), N(L.weight.scale), ew)
             gm += a
             gr += b_
         kb = L1.bias.draw_key
-        eb = orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, 0, tuple(L1.bias.shape))
+        eb = orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, 0, tuple(L1.bias.shape), kb.gen)
         g_rho_b1 += orc.sample_affine_bwd(g1.sum(0).astype(np.float32), N(L1.bias.scale), eb)[1]
     sc = 1.0 / (4 * 4)
     for (L, gm, gr) in ((L0, g_mu0, g_rho0), (L1, g_mu1, g_rho1)):
@@ -811,7 +814,7 @@ def _bwd_case(env, S, M, N, K, seed, shared_x=False):
     gy = torch.randn(S, M, N, generator=gen)
     key = DrawKey(99 + seed, 21, 0, S, 7)
     orc = env["orc"]
-    eps = [orc.eps_fill(key.seed, key.stream, s, key.epoch_host, 0, (N, K)) for s in range(S)]
+    eps = [orc.eps_fill(key.seed, key.stream, s, key.epoch_host, 0, (N, K), key.gen) for s in range(S)]
     return mu, rho, x, gy, key, eps
 
 
@@ -914,7 +917,7 @@ def test_bias_gradient_fused_into_weight_gradient(env, mode, M):
     want_rho = np.zeros(Nn)
     for s_ in range(S):
         cs = (N(gy[s_]) if rnd is None else rnd(N(gy[s_]))).astype(np.float64).sum(0)
-        eb = orc.eps_fill(kb.seed, kb.stream, s_, kb.epoch_host, 0, (Nn,))
+        eb = orc.eps_fill(kb.seed, kb.stream, s_, kb.epoch_host, 0, (Nn,), kb.gen)
         a, b = orc.sample_affine_bwd(np.ones(Nn, np.float32), N(rhob), eb)
         want_mu += cs * a
         want_rho += cs * b
@@ -923,7 +926,7 @@ def test_bias_gradient_fused_into_weight_gradient(env, mode, M):
         assert allclose_scaled(N(got), want_mu, tol)
     for got in (g_rho_b, g_rho_b0):
         assert allclose_scaled(N(got), want_rho, tol)
-    ew = [orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, (Nn, K)) for s_ in range(S)]
+    ew = [orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, (Nn, K), kw.gen) for s_ in range(S)]
     wm, wr, _ = _oracle_linear_bwd(orc, mu, rho, x, gy, ew, False, rounder=rnd)
     assert allclose_scaled(N(g_mu_w), wm, tol) and allclose_scaled(N(g_rho_w), wr, tol)
     del n0
@@ -1043,11 +1046,11 @@ def test_sampled_conv2d_backward_vs_float64_autograd(env, cfg, mode):
     mb64, rb64 = mub.double().requires_grad_(True), rhob.double().requires_grad_(True)
     ys = []
     for s_ in range(S):
-        ew = torch.from_numpy(orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, tuple(mu.shape))).double()
+        ew = torch.from_numpy(orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, tuple(mu.shape), kw.gen)).double()
         w = m64 + (1e-10 + torch.nn.functional.softplus(r64)) * ew
         b_ = None
         if bias:
-            eb = torch.from_numpy(orc.eps_fill(kb.seed, kb.stream, s_, kb.epoch_host, 0, (O,))).double()
+            eb = torch.from_numpy(orc.eps_fill(kb.seed, kb.stream, s_, kb.epoch_host, 0, (O,), kb.gen)).double()
             b_ = mb64 + (1e-10 + torch.nn.functional.softplus(rb64)) * eb
         ys.append(torch.nn.functional.conv2d(x64 if shared else x64[s_], w, b_, st, pd, dl))
     y64 = torch.stack(ys)
@@ -1115,8 +1118,8 @@ def test_random_shapes_forward_and_backward_vs_oracle(env, S, M, Nn, K, bias, sh
     md, rd = mu.to(dev).requires_grad_(True), rho.to(dev).requires_grad_(True)
     mbd, rbd = (mub.to(dev).requires_grad_(True), rhob.to(dev).requires_grad_(True)) if bias else (None, None)
     y = env["ops"].linear_sampled(xd, md, rd, mbd, rbd, kw, kb if bias else None, shared)
-    eps = [orc.eps_fill(kw.seed, kw.stream, 2 + s_, kw.epoch_host, 0, (Nn, K)) for s_ in range(S)]
-    epsb = [orc.eps_fill(kb.seed, kb.stream, 2 + s_, kb.epoch_host, 0, (Nn,)) for s_ in range(S)]
+    eps = [orc.eps_fill(kw.seed, kw.stream, 2 + s_, kw.epoch_host, 0, (Nn, K), kw.gen) for s_ in range(S)]
+    epsb = [orc.eps_fill(kb.seed, kb.stream, 2 + s_, kb.epoch_host, 0, (Nn,), kb.gen) for s_ in range(S)]
     for s_ in range(S):
         w = orc.sample_affine(mu.numpy(), rho.numpy(), eps[s_])
         b_ = orc.sample_affine(mub.numpy(), rhob.numpy(), epsb[s_]) if bias else None
@@ -1157,7 +1160,7 @@ def test_random_shapes_bf16_mode_vs_exact_oracle(env, S, M, Nn, K, bias, shared,
     xd = x.to(dev).to(adt).requires_grad_(True)
     md, rd = mu.to(dev).requires_grad_(True), rho.to(dev).requires_grad_(True)
     y = env["ops"].linear_sampled(xd, md, rd, None, None, kw, None, shared, compute="bf16", out_dtype=adt)
-    eps = [orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, (Nn, K)) for s_ in range(S)]
+    eps = [orc.eps_fill(kw.seed, kw.stream, s_, kw.epoch_host, 0, (Nn, K), kw.gen) for s_ in range(S)]
     for s_ in range(S):
         w = orc.sample_affine(mu.numpy(), rho.numpy(), eps[s_])
         assert allclose_scaled(N(y[s_].float()), orc.linear(N(xr if shared else xr[s_]), w, None), 3e-2)
@@ -1362,7 +1365,7 @@ def test_empty_batch_and_single_row_edges(env):
         k1 = DrawKey(4, 2, 5, 1, 0)
         xx = torch.randn(1, 1, K)
         got = env["ops"].linear_sampled(xx.to(dev), m1.to(dev), r1.to(dev), None, None, k1, None, False)
-        w = orc.sample_affine(m1.numpy(), r1.numpy(), orc.eps_fill(k1.seed, k1.stream, 5, k1.epoch_host, 0, (Nn, K)))
+        w = orc.sample_affine(m1.numpy(), r1.numpy(), orc.eps_fill(k1.seed, k1.stream, 5, k1.epoch_host, 0, (Nn, K), k1.gen))
         assert allclose(N(got)[0], orc.linear(xx[0].numpy(), w))
 
 

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     # pure host queries only -- nothing is launched without a GPU
-    assert lib.bnn_abi_version() == 1
+    assert lib.bnn_abi_version() == 2
     assert lib.bnn_arch() == b"gfx950"
     assert lib.bnn_kl_workspace_bytes(6) > 0
 

@@ -40,6 +40,43 @@ def test_eps_stream_is_standard_normal():
     assert np.array_equal(e[:61], orc.eps_fill(0xC0FFEE, 3, 5, 7, 0, (61,)))
 
 
+def test_philox7_published_kat():
+    # Random123 kat_vectors, philox4x32 7 rounds (the generator of BNN_GEN_PHILOX7_U16); 10 rounds through the same entry
+    assert [hex(v) for v in orc.philox4x32_r([0, 0, 0, 0], [0, 0], 7)] == ['0x5f6fb709', '0xd893f64', '0x4f121f81', '0x4f730a48']
+    assert [hex(v) for v in orc.philox4x32_r([0xffffffff] * 4, [0xffffffff] * 2, 7)] == \
+        ['0x5207ddc2', '0x45165e59', '0x4d8ee751', '0x8c52f662']
+    assert [hex(v) for v in orc.philox4x32_r([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], 7)] == \
+        ['0x4dfccaba', '0x190a87f0', '0xc47362ba', '0xb6b5242a']
+    assert np.array_equal(orc.philox4x32_r([1, 2, 3, 4], [5, 6], 10), orc.philox4x32_10([1, 2, 3, 4], [5, 6]))
+
+
+def test_eps_stream_u16_is_standard_normal():
+    """BNN_GEN_PHILOX7_U16 (eight eps per Philox4x32-7 block from 16-bit uniforms -- the bf16 mode's stream): moments, a
+    Kolmogorov-Smirnov test against the normal CDF, independence of neighbours, the truncation the 16-bit radius implies, and
+    the addressing (streams / samples / epochs distinct, prefixes stable, not the default stream)."""
+    from scipy import stats
+    n = 1 << 21
+    e = orc.eps_fill(0xC0FFEE, 3, 5, 7, 0, (n,), 1)
+    assert np.isfinite(e).all()
+    assert abs(e.mean()) < 3e-3 and abs(e.std() - 1) < 3e-3
+    assert abs((e ** 3).mean()) < 1.5e-2 and abs((e ** 4).mean() - 3) < 4e-2
+    assert np.abs(e).max() <= 4.86                                   # r(2^-17) = sqrt(34 ln 2) = 4.855
+    d, pval = stats.kstest(e.astype(np.float64), "norm")
+    assert d < 1.5e-3 and pval > 1e-3, (d, pval)
+    # the two outputs of a Box-Muller pair, neighbouring pairs and neighbouring blocks are uncorrelated
+    for lag in (1, 2, 8):
+        c = float(np.mean(e[:-lag].astype(np.float64) * e[lag:]))
+        assert abs(c) < 4e-3, (lag, c)
+    c2 = float(np.mean((e[:-1].astype(np.float64) ** 2 - 1) * (e[1:].astype(np.float64) ** 2 - 1)))      # cos^2 / sin^2 of one pair share r
+    assert abs(c2) < 2e-2, c2
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 3, 6, 7, 0, (64,), 1))
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 4, 5, 7, 0, (64,), 1))
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 3, 5, 8, 0, (64,), 1))
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 3, 5, 7, 1, (64,), 1))
+    assert not np.array_equal(e[:64], orc.eps_fill(0xC0FFEE, 3, 5, 7, 0, (64,), 0))
+    assert np.array_equal(e[:61], orc.eps_fill(0xC0FFEE, 3, 5, 7, 0, (61,), 1))
+
+
 def test_weightnormal_sigma_sample_kl():
     g = load_golden("weightnormal_5x6x7")
     assert allclose(orc.sigma(g["rho"]), g["sigma"])

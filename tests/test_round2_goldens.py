@@ -117,13 +117,13 @@ def test_shipped_mnist_net_end_to_end(env):
     pre_np = N(pre)
     for s in range(2):
         kw, kb = conv.weight.draw_key, conv.bias.draw_key
-        w = orc.sample_affine(N(conv.weight.mean), N(conv.weight.scale), orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, 0, tuple(conv.weight.shape)))
-        b = orc.sample_affine(N(conv.bias.mean), N(conv.bias.scale), orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, 0, tuple(conv.bias.shape)))
+        w = orc.sample_affine(N(conv.weight.mean), N(conv.weight.scale), orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, 0, tuple(conv.weight.shape), kw.gen))
+        b = orc.sample_affine(N(conv.bias.mean), N(conv.bias.scale), orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, 0, tuple(conv.bias.shape), kb.gen))
         h = orc.conv2d(pre_np, w, b, stride=(2, 2), padding=(1, 1))
         h = np.where(h > 0, h, np.expm1(h)).reshape(h.shape[0], -1).astype(np.float32)          # ELU
         kw, kb = lin.weight.draw_key, lin.bias.draw_key
-        w = orc.sample_affine(N(lin.weight.mean), N(lin.weight.scale), orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, 0, tuple(lin.weight.shape)))
-        b = orc.sample_affine(N(lin.bias.mean), N(lin.bias.scale), orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, 0, tuple(lin.bias.shape)))
+        w = orc.sample_affine(N(lin.weight.mean), N(lin.weight.scale), orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, 0, tuple(lin.weight.shape), kw.gen))
+        b = orc.sample_affine(N(lin.bias.mean), N(lin.bias.scale), orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, 0, tuple(lin.bias.shape), kb.gen))
         z = orc.linear(h, w, b).astype(np.float64)
         z = np.exp(z - z.max(-1, keepdims=True))
         want = (z / z.sum(-1, keepdims=True)).astype(np.float32)

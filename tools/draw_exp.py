@@ -9,7 +9,8 @@ import bench
 lib = _lib.load(); dev = torch.device("cuda:0")
 post = [[t.to(dev) for t in p] for p in bench.posteriors(0)]
 S = int(os.environ.get("S", "8"))
-layers = [(mw, rw, mb, rb, DrawKey(1, 2 * i + 1, 0, S, 0), DrawKey(1, 2 * i + 2, 0, S, 0)) for i, (mw, rw, mb, rb) in enumerate(post)]
+G = int(os.environ.get('GEN', '0'))
+layers = [(mw, rw, mb, rb, DrawKey(1, 2 * i + 1, 0, S, 0, gen=G), DrawKey(1, 2 * i + 2, 0, S, 0, gen=G)) for i, (mw, rw, mb, rb) in enumerate(post)]
 us = bench._graph_time(lambda: ops.draw_layers(layers, S), dev)
 mus = [t for p in post for t in (p[0].reshape(-1), p[2])]
 rhos = [t for p in post for t in (p[1].reshape(-1), p[3])]
@@ -19,4 +20,4 @@ def with_kl():
     ops.draw_layers(layers, S, kl=h)
     ops._tls.kl_carry = None
 us_kl = bench._graph_time(with_kl, dev)
-print("BNN_DRAW_EXP=%s S=%d: draw %.2f us, draw + KL first pass %.2f us" % (os.environ.get("BNN_DRAW_EXP", "0"), S, us, us_kl))
+print("GEN=%d BNN_DRAW_EXP=%s S=%d: draw %.2f us, draw + KL first pass %.2f us" % (G, os.environ.get("BNN_DRAW_EXP", "0"), S, us, us_kl))

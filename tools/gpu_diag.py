@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 key = DrawKey(0xDEADBEEF12345, 9, 0, 1, 3)
 n = 1 << 22
 e = ops.eps_philox((n,), key, dev)[0].cpu().numpy()
-w = orc.eps_fill(key.seed, key.stream, 0, key.epoch_host, 0, (n,))
+w = orc.eps_fill(key.seed, key.stream, 0, key.epoch_host, 0, (n,), key.gen)
 d = np.abs(e - w)
 print("eps: max abs err %.3e  rms err %.3e  at |eps|=%.3f" % (d.max(), np.sqrt((d**2).mean()), abs(w[d.argmax()])))
 for (M, K, Nn) in [(512, 784, 1200), (512, 1200, 1200), (512, 1200, 10), (4096, 4096, 4096)]:
@@ -24,8 +24,8 @@ for (M, K, Nn) in [(512, 784, 1200), (512, 1200, 1200), (512, 1200, 10), (4096, 
     x = torch.randn(M, K, device=dev)
     y = layer(x).detach().cpu().numpy()
     kw, kb = layer.weight.draw_key, layer.bias.draw_key
-    ew = orc.eps_fill(kw.seed, kw.stream, 0, kw.epoch_host, 0, (Nn, K))
-    eb = orc.eps_fill(kb.seed, kb.stream, 0, kb.epoch_host, 0, (Nn,))
+    ew = orc.eps_fill(kw.seed, kw.stream, 0, kw.epoch_host, 0, (Nn, K), kw.gen)
+    eb = orc.eps_fill(kb.seed, kb.stream, 0, kb.epoch_host, 0, (Nn,), kb.gen)
     wo = orc.sample_affine(layer.weight.mean.detach().cpu().numpy(), layer.weight.scale.detach().cpu().numpy(), ew)
     bo = orc.sample_affine(layer.bias.mean.detach().cpu().numpy(), layer.bias.scale.detach().cpu().numpy(), eb)
     ws = layer.sampled[0].detach().cpu().numpy()
