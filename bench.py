@@ -13,8 +13,14 @@ asynchronously so that it runs under the next step.
 rank (`distributed.shard_samples`), value = 8 * steps / time; the weak-scaling number (8 samples on
 every rank, value = N * 8 * steps / time) rides along under "weak".
 
-Prints ONE JSON line (rank 0).  Extra keys: `checked` (one more replay of the timed graph compared
-with the CPU oracle on the replay's own draw keys -- a checker, never timed), `roofline` (dominant
+Timing: `--windows` (default 25) repetitions of the timed window of `--steps` steps (barrier + synchronize around every
+window) inside one run; `value` / `ms_per_step` are the MEDIAN window, `timing` holds the fastest and slowest.
+A run whose oracle check fails, or that leaves the device error word set, prints its line with a `failed` list and exits
+non-zero.
+
+Prints ONE JSON line (rank 0).  Extra keys: `checked` / `checked_f32` (one more replay of the timed object compared
+with the CPU oracle on the replay's own draw keys -- a checker, never timed; N > 1: the all-reduced buffer against global
+sample ids, every rank replays, rank 0 compares), `device_error_word`, `roofline` (dominant
 kernel, measured live with events on the launch stream), `roofline_conv_lenet` / `roofline_conv_cifar`
 / `roofline_wide_f32` (configs[2], [3], [4] layer launches), `cpu_baseline` (torch-CPU port of the
 reference, N = 1 only), `f32` (same step in the fp32 parity mode), `train` (N = 1: the reference's
@@ -301,41 +307,56 @@ class PipelinedSteps:
 
 
 # ------------------------------------------------------------------------------------------ checker
-def oracle_check(step, post, x_cpu, mode, rows=64, tap=None, replay=True):
-    """CHECKER -- never timed, never on the product path.  Replays the step ONCE more and compares it with
-    the CPU oracle (oracle/bnn_oracle.c; pinned to the reference by tests/test_oracle_golden.py) evaluated
-    on the draw keys this replay used: KL scalar, `rows` rows of the predictive mean and (if `tap`, a
-    (S, rows, N2) buffer a forward hook on layer 2 fills) of the layer-2 output.  bf16 mode: the oracle is
-    fed what the kernels feed the MFMA -- bf16-rounded inputs, drawn weights and hidden activations, fp32 bias.
-    replay=False: nothing is launched -- the result the step's LAST replay left behind is checked (epoch = cell - 1): the way
-    to check a result that was produced while other steps were in flight on other streams (PipelinedSteps).
-    Returns a dict of the measured errors and the tolerances they are judged by."""
-    import numpy as np
-    from oracle import oracle as orc
-    assert step.world == 1
+# bf16 mode: a drawn weight (or hidden activation) within the eps twin's 1e-6 of a bf16 rounding boundary rounds the other way on
+# one side (one bf16 ulp on ~0.3 % of the weights).  Measured on MI355X boxes over rounds 2 and 3: 2.2e-3 .. 2.9e-3 of the
+# output scale (profiles/r02_bench_path_check.jsonl, gpurun_out/bench_path_check.jsonl).  Tolerance: TWICE that maximum =
+# 1.5 * 2^-8 of the output scale (round 2 allowed a whole bf16 ulp, 2^-7: a real regression of 3 x would have passed).
+TOL_BF16 = 1.5 * 2.0 ** -8
+TOL_F32 = 1e-5
+
+
+def oracle_collect(step, replay=True):
+    """Run the step ONCE more (every rank: for N > 1 the replay ends in the step's all-reduce) and return what the check needs:
+    the packed result as a numpy array -- for N > 1 the ALL-REDUCED buffer -- and the device epoch that replay's launches read.
+    replay=False: nothing is launched; the result the step's LAST replay left behind (epoch = cell - 1): the way to check a result
+    that was produced while other steps were in flight on other streams (PipelinedSteps, N = 1)."""
     dev = step.x.device
     cell = step.cell if getattr(step, "cell", None) is not None else step.gen.epoch_dev(dev)
     torch.cuda.synchronize(dev)
     if replay:
         e_dev = int(cell[0].item())                 # the epoch this replay's launches will read
         out = step.run()
+        step.finish()                               # N > 1: the asynchronous all-reduce of this replay
         torch.cuda.synchronize(dev)
         e_after = int(cell[0].item())
     else:
         e_after = int(cell[0].item())
         e_dev = e_after - 1                         # the epoch the last replay read (it bumped the word at its end)
         out = step.packed
-    got = out.detach().float().cpu().numpy().copy()
-    S, T = step.samples, step.T
+    return out.detach().float().cpu().numpy().copy(), e_dev, e_after
+
+
+def oracle_evaluate(got, keys, e_dev, e_after, post, x_cpu, mode, nsamples, world=1, rows=64, tap=None):
+    """CHECKER -- never timed, never on the product path.  `got`: a step's packed result [6 KL slots | scalar slot | B x 10
+    predictive mean]; N = 1: slot 6 holds the KL scalar; N > 1 (the all-reduced buffer): slots 0..5 hold each tensor's KL SUM
+    over all ranks' shards and the scalar is formed here as the reference does (mean over the tensor, mean over the tensors,
+    loss.py:28,38).  Compared with the CPU oracle (oracle/bnn_oracle.c, pinned to the reference by tests/test_oracle_golden.py)
+    on the draw keys of that replay with GLOBAL MC sample ids 0 .. nsamples - 1: KL scalar, `rows` rows of the predictive mean
+    and (if `tap`, a (S, rows, N2) copy of the layer-2 output a forward hook made) of the layer-2 output.  bf16 mode: the
+    oracle is fed what the kernels feed the MFMA -- bf16-rounded inputs, drawn weights and hidden activations, fp32 bias."""
+    import numpy as np
+    from oracle import oracle as orc
+    T = 2 * len(post)
     rnd = orc.bf16_round if mode == "bf16" else (lambda a: np.asarray(a, np.float32))
     h0 = rnd(x_cpu[:rows].float().numpy())
     pred = np.zeros((rows, DIMS[-1]), np.float64)
     h2_ref = []
-    for s in range(S):
+    for s in range(nsamples):
         h = h0
-        for li, ((mw, rw, mb, rb), (kw, kb)) in enumerate(zip(post, step.keys)):
-            ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0 + s, kw.epoch_host, e_dev + kw.epoch_dev_delta, tuple(mw.shape), kw.gen)
-            eb = orc.eps_fill(kb.seed, kb.stream, kb.sample0 + s, kb.epoch_host, e_dev + kb.epoch_dev_delta, tuple(mb.shape), kb.gen)
+        for li, ((mw, rw, mb, rb), (kw, kb)) in enumerate(zip(post, keys)):
+            # global sample id s (a rank's key starts at its own sample0: the stream is addressed by the id, not by the rank)
+            ew = orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, e_dev + kw.epoch_dev_delta, tuple(mw.shape), kw.gen)
+            eb = orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, e_dev + kb.epoch_dev_delta, tuple(mb.shape), kb.gen)
             w = rnd(orc.sample_affine(mw.numpy(), rw.numpy(), ew))
             b = orc.sample_affine(mb.numpy(), rb.numpy(), eb)
             h = orc.linear(h, w, b)
@@ -344,19 +365,19 @@ def oracle_check(step, post, x_cpu, mode, rows=64, tap=None, replay=True):
             if li == 1:
                 h2_ref.append(h)
         pred += h
-    pred /= S
+    pred /= nsamples
     tensors = []
     for mw, rw, mb, rb in post:
         tensors += [(mw.numpy(), rw.numpy(), 0.0, 0.1), (mb.numpy(), rb.numpy(), 0.0, 0.1)]
     kl_ref = orc.kl_divergence(tensors)
-    kl_got = float(got[T])
+    if world == 1:
+        kl_got = float(got[T])
+    else:
+        kl_got = float(np.mean([float(got[t]) / tensors[t][0].size for t in range(T)]))
     pm = got[T + 1:].reshape(BATCH, DIMS[-1])[:rows].astype(np.float64)
     rms = float(np.sqrt((pred ** 2).mean()))
-    # bf16 mode: a drawn weight (or hidden activation) within the eps twin's 1e-6 of a bf16 rounding boundary rounds the
-    # other way on one side (one bf16 ulp on ~0.3 % of the weights); measured on the box: 2.2e-3 .. 2.9e-3 of the output
-    # scale over replays (gpurun_out/bench_path_check.jsonl).  Tolerance: ONE bf16 ulp (2^-7) of the output scale.
-    tol = 2.0 ** -7 if mode == "bf16" else 1e-5
-    res = {"mode": mode, "rows": rows, "epoch_dev": e_dev, "epoch_advanced": e_after == e_dev + 1,
+    tol = TOL_BF16 if mode == "bf16" else TOL_F32
+    res = {"mode": mode, "rows": rows, "samples": nsamples, "world": world, "epoch_dev": e_dev, "epoch_advanced": e_after == e_dev + 1,
            "kl": kl_got, "kl_ref": kl_ref, "kl_rel_err": abs(kl_got - kl_ref) / abs(kl_ref), "kl_tol": 1e-5,
            "pred_max_err": float(np.abs(pm - pred).max()), "pred_rms": rms, "tol": tol,
            "pred_tol_abs": tol * max(1.0, rms)}
@@ -371,6 +392,15 @@ def oracle_check(step, post, x_cpu, mode, rows=64, tap=None, replay=True):
         ok = ok and bool((np.abs(t - ref) <= res["h2_tol_abs"] + ulp).all())
     res["ok"] = bool(ok)
     return res
+
+
+def oracle_check(step, post, x_cpu, mode, rows=64, tap=None, replay=True, evaluate=True):
+    """oracle_collect + oracle_evaluate.  N > 1: every rank replays (the collective), `evaluate` says who compares (rank 0);
+    the global sample count is the step's `total`."""
+    got, e_dev, e_after = oracle_collect(step, replay)
+    if not evaluate:
+        return None
+    return oracle_evaluate(got, step.keys, e_dev, e_after, post, x_cpu, mode, step.total, step.world, rows, tap)
 
 
 class TrainStep:
@@ -437,6 +467,7 @@ class TrainStep:
 
 
 def time_steps(step, steps, warmup, world, dev):
+    """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks."""
     for _ in range(warmup):
         step.run()
     if world > 1:
@@ -456,6 +487,22 @@ def time_steps(step, steps, warmup, world, dev):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     return dt
+
+
+def time_windows(step, steps, warmup, world, dev, windows):
+    """`windows` repetitions of the timed window of time_steps (the warm-up before the first only) -> the list of their
+    durations.  A 20-step window is ~1 ms: one window is one sample of a noisy quantity, so the line reports the MEDIAN
+    window (and the fastest and slowest next to it); every window is `steps` complete steps between barriers."""
+    out = [time_steps(step, steps, warmup, world, dev)]
+    for _ in range(max(1, windows) - 1):
+        out.append(time_steps(step, steps, 0, world, dev))
+    return out
+
+
+def _median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
 
 
 def _time_launches(fn, dev, iters, warm=5):
@@ -739,6 +786,8 @@ def main(argv=None):
                     help="N > 1 headline: strong = the 8 global MC samples sharded 8/N per GPU (SURVEY 8e); weak = 8 per GPU")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("BNN_BENCH_INFLIGHT", "4")),
                     help="N = 1 forward: independent steps in flight on separate streams (1 = one stream)")
+    ap.add_argument("--windows", type=int, default=int(os.environ.get("BNN_BENCH_WINDOWS", "25")),
+                    help="repetitions of the timed window of --steps steps inside this run; the line reports the median window")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the configs[2..4] / K1 / K3 roofline legs")
@@ -778,7 +827,16 @@ def main(argv=None):
     bnn.manual_seed(2)
 
     strong = world > 1 and args.scaling == "strong" and SAMPLES % world == 0
-    results, checked, weak, pipeline = {}, None, None, None
+    results, checked, weak, pipeline, spread = {}, {}, None, None, {}
+    failures = []
+
+    def summarise(dts, total, steps):
+        """median / fastest / slowest window -> (value, ms_per_step, steps), {window statistics}"""
+        med, lo, hi = _median(dts), min(dts), max(dts)
+        return (total * steps / med, med / steps * 1e3, steps), {
+            "windows": len(dts), "steps_per_window": steps, "ms_per_step_median": round(med / steps * 1e3, 4),
+            "ms_per_step_min": round(lo / steps * 1e3, 4), "ms_per_step_max": round(hi / steps * 1e3, 4)}
+
     for mode in ([args.dtype] + (["f32"] if (args.dtype != "f32" and world == 1) else [])):
         bnn.set_compute(mode)
         # bf16 mode: the synthetic batch is resident in HBM as bf16 (the first layer would round its
@@ -792,42 +850,59 @@ def main(argv=None):
         step = Step(net, x_in, rank, world, not args.no_graph, **skw)
         steps = args.steps if mode == args.dtype else max(10, args.steps // 4)
         total = SAMPLES if strong else world * SAMPLES
-        dt = time_steps(step, steps, args.warmup, world, dev)
-        results[mode] = (total * steps / dt, dt / steps * 1e3, steps)
-        if mode == args.dtype and world == 1:
-            checked = oracle_check(step, post, x_cpu, mode)
+        windows = args.windows if mode == args.dtype else max(3, args.windows // 5)
+        results[mode], spread[mode] = summarise(time_windows(step, steps, args.warmup, world, dev, windows), total, steps)
+        # one more replay of the TIMED object against the oracle -- both modes, every N (N > 1: the all-reduced buffer, global
+        # sample ids; every rank replays, rank 0 compares)
+        chk = oracle_check(step, post, x_cpu, mode, evaluate=(rank == 0))
+        if rank == 0:
+            checked[mode] = chk
+            if not chk["ok"]:
+                failures.append("oracle check of the timed step failed (%s mode)" % mode)
         if use_pipe:
             # throughput pipeline: `inflight` steps on as many streams; the single-stream number above becomes the latency
-            single = results[mode]
+            single, single_spread = results[mode], spread[mode]
             pipe = PipelinedSteps(net, x_in, args.inflight, rank, world, **skw)
-            pdt = time_steps(pipe, steps, args.warmup, world, dev)
-            piped = (total * steps / pdt, pdt / steps * 1e3, steps)
-            # both are K timed steps between barriers (max over ranks, so every rank decides alike): the line reports the
-            # higher throughput and says which arrangement it was
-            results[mode] = piped if piped[0] >= single[0] else single
-            pipeline = {"steps_in_flight": args.inflight, "untimed_preroll_steps": int(os.environ.get("BNN_BENCH_PREROLL", "256")), "reported": "pipelined" if piped[0] >= single[0] else "single_stream",
+            piped, pipe_spread = summarise(time_windows(pipe, steps, args.warmup, world, dev, windows), total, steps)
+            # both are windows of K timed steps between barriers (max over ranks, so every rank decides alike): the line reports
+            # the higher throughput and says which arrangement it was
+            use_piped = piped[0] >= single[0]
+            results[mode], spread[mode] = (piped, pipe_spread) if use_piped else (single, single_spread)
+            pipeline = {"steps_in_flight": args.inflight, "untimed_preroll_steps": int(os.environ.get("BNN_BENCH_PREROLL", "256")),
+                        "reported": "pipelined" if use_piped else "single_stream",
                         "pipelined_value": round(piped[0], 1), "pipelined_ms_per_step": round(piped[1], 4),
+                        "pipelined_windows": pipe_spread,
                         "single_stream_value": round(single[0], 1),
                         "single_stream_ms_per_step": round(single[1], 4),
+                        "single_stream_windows": single_spread,
                         "note": "pipelined = `steps_in_flight` complete steps in flight on as many streams: THROUGHPUT (K complete "
-                                "steps / wall time); one step's latency is single_stream_ms_per_step"}
+                                "steps / wall time); one step's LATENCY is single_stream_ms_per_step"}
             if world == 1:
                 # what the steps' LAST replays -- executed while the others were in flight -- left behind, against the oracle
                 pchks = [oracle_check(st, post, x_cpu, mode, replay=False) for st in pipe.steps]
                 pipeline.update({"checked_in_flight_results_ok": all(c["ok"] for c in pchks),
                                  "in_flight_pred_max_err": max(c["pred_max_err"] for c in pchks),
                                  "in_flight_epochs": [c["epoch_dev"] for c in pchks]})
+                if not pipeline["checked_in_flight_results_ok"]:
+                    failures.append("oracle check of the in-flight results failed")
             del pipe
         if mode == args.dtype and strong:
             if use_pipe:
                 wstep = PipelinedSteps(net, x_in, args.inflight, rank, world)
             else:
                 wstep = Step(net, x_in, rank, world, not args.no_graph)
-            wdt = time_steps(wstep, steps, args.warmup, world, dev)
-            weak = (world * SAMPLES * steps / wdt, wdt / steps * 1e3)
+            wres, _ = summarise(time_windows(wstep, steps, args.warmup, world, dev, max(3, windows // 5)), world * SAMPLES, steps)
+            weak = (wres[0], wres[1])
             del wstep
         del step
     bnn.set_compute(args.dtype)
+    # the device error word: a kernel whose bounded hand-off wait gave up has skipped its stores and said so there
+    try:
+        _lib.check_device(dev)
+        device_word = "clear"
+    except Exception as e:      # BnnHipError(BNN_E_DEVICE)
+        device_word = "SET: %s" % e
+        failures.append("device error word set after the timed runs")
 
     # training step (own copy of the model: Adam moves the parameters)
     train = None
@@ -861,8 +936,13 @@ def main(argv=None):
         if weak is not None:
             line["weak"] = {"value": round(weak[0], 1), "ms_per_step": round(weak[1], 4), "samples_per_step_per_gpu": SAMPLES,
                             "note": "weak scaling: 8 MC samples on every GPU (global predictive mean over 8 N)"}
-        if checked is not None:
-            line["checked"] = checked
+        line["timing"] = dict(spread[args.dtype], note="value / ms_per_step = the MEDIAN of `windows` timed windows of `steps` steps each "
+                              "(barrier + synchronize around every window)")
+        line["device_error_word"] = device_word
+        if args.dtype in checked:
+            line["checked"] = checked[args.dtype]
+        if "f32" in checked and args.dtype != "f32":
+            line["checked_f32"] = checked["f32"]
         if pipeline is not None:
             line["config"]["pipeline"] = pipeline
         if train is not None:
@@ -888,11 +968,17 @@ def main(argv=None):
             line["roofline_wide_f32"] = wide_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(post, x_cpu)
+        if failures:
+            line["failed"] = failures       # a wrong-result run publishes no headline: the process exits non-zero
         print(json.dumps(line), flush=True)
+    rc = 1 if failures else 0
     if world > 1:
+        t = torch.tensor([rc], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)      # every rank leaves with rank 0's verdict
+        rc = int(t.item())
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
-    return 0
+    return rc
 
 
 if __name__ == "__main__":

@@ -47,6 +47,59 @@ def test_bench_strong_scaling_shards_cover_the_samples():
         assert ids == list(range(bench.SAMPLES))
 
 
+def test_multi_gpu_check_arithmetic_on_an_emulated_all_reduce():
+    """bench.oracle_evaluate for N > 1, on CPU: the packed buffers of two ranks of a strong-scaling run are built from the
+    oracle itself -- rank r holds global MC samples [4 r, 4 r + 4) scaled by 1 / 8 and the KL SUMS of its shard of every
+    posterior tensor (distributed.shard_range) -- and added as the one all-reduce adds them.  The check must accept that
+    buffer (KL scalar from the six sums, predictive mean over global sample ids 0..7) and reject a buffer with one rank's
+    samples drawn on the wrong ids, or with one tensor's KL shard missing."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from bayesianneuralnetworks_amd import distributed as bd
+    from bayesianneuralnetworks_amd._rng import DrawKey, GEN_PHILOX7_U16
+    from oracle import oracle as orc
+    post = bench.posteriors(0)
+    x_cpu = torch.randn(bench.BATCH, bench.DIMS[0], generator=torch.Generator().manual_seed(1))
+    rows, world, S, e_dev = 4, 2, bench.SAMPLES, 3
+    T = 2 * len(post)
+    keys = [(DrawKey(2, 2 * i + 1, 0, S // world, 11, gen=GEN_PHILOX7_U16), DrawKey(2, 2 * i + 2, 0, S // world, 11, gen=GEN_PHILOX7_U16))
+            for i in range(len(post))]                           # rank 0's keys: sample0 = 0, 4 samples
+
+    def rank_buffer(r, id_shift=0, drop_kl=None):
+        buf = np.zeros(T + 1 + bench.BATCH * bench.DIMS[-1], np.float64)
+        t = 0
+        for mw, rw, mb, rb in post:
+            for mu, rho in ((mw, rw), (mb, rb)):
+                lo, hi = bd.shard_range(mu.numel(), r, world)
+                if hi > lo and t != drop_kl:
+                    buf[t] = orc.kl_sum(mu.reshape(-1)[lo:hi].numpy(), rho.reshape(-1)[lo:hi].numpy(), 0.0, 0.1)
+                t += 1
+        pred = np.zeros((bench.BATCH, bench.DIMS[-1]))
+        s0, cnt = bd.shard_samples(S, r, world)
+        for s in range(s0 + id_shift, s0 + id_shift + cnt):
+            h = orc.bf16_round(x_cpu[:rows].numpy())
+            for li, ((mw, rw, mb, rb), (kw, kb)) in enumerate(zip(post, keys)):
+                w = orc.bf16_round(orc.sample_affine(mw.numpy(), rw.numpy(), orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, e_dev, tuple(mw.shape), kw.gen)))
+                b = orc.sample_affine(mb.numpy(), rb.numpy(), orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, e_dev, tuple(mb.shape), kb.gen))
+                h = orc.linear(h, w, b)
+                if li < len(post) - 1:
+                    h = orc.bf16_round(np.maximum(h, 0.0))
+            pred[:rows] += h / S
+        buf[T + 1:] = pred.reshape(-1)
+        return buf
+
+    r0, r1 = rank_buffer(0), rank_buffer(1)
+    good = bench.oracle_evaluate((r0 + r1).astype(np.float32), keys, e_dev, e_dev + 1, post, x_cpu, "bf16", S, world, rows=rows)
+    assert good["ok"] and good["world"] == 2 and good["samples"] == 8, good
+    assert good["kl_rel_err"] < 1e-6 and good["pred_max_err"] < 1e-3
+    bad = bench.oracle_evaluate((r0 + rank_buffer(1, id_shift=1)).astype(np.float32), keys, e_dev, e_dev + 1, post, x_cpu, "bf16", S, world, rows=rows)
+    assert not bad["ok"] and bad["kl_rel_err"] < 1e-6            # wrong sample ids on rank 1: the predictive mean is off, the KL is not
+    bad = bench.oracle_evaluate((r0 + rank_buffer(1, drop_kl=2)).astype(np.float32), keys, e_dev, e_dev + 1, post, x_cpu, "bf16", S, world, rows=rows)
+    assert not bad["ok"] and bad["kl_rel_err"] > 1e-3
+    stale = bench.oracle_evaluate((r0 + r1).astype(np.float32), keys, e_dev, e_dev, post, x_cpu, "bf16", S, world, rows=rows)
+    assert not stale["ok"]                                       # the replay did not advance the device epoch
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
 def test_timed_graph_replays_match_oracle(mode):

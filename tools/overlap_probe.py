@@ -10,7 +10,7 @@ import bench
 lib = _lib.load(); dev = torch.device("cuda:0")
 S, B = 8, 512
 post = [[t.to(dev) for t in p] for p in bench.posteriors(0)]
-layers = [(mw, rw, mb, rb, DrawKey(1, 2 * i + 1, 0, S, 0), DrawKey(1, 2 * i + 2, 0, S, 0)) for i, (mw, rw, mb, rb) in enumerate(post)]
+layers = [(mw, rw, mb, rb, DrawKey(1, 2 * i + 1, 0, S, 0, gen=1), DrawKey(1, 2 * i + 2, 0, S, 0, gen=1)) for i, (mw, rw, mb, rb) in enumerate(post)]
 pre = ops.draw_layers(layers, S)
 h = torch.zeros(S, B, 1216, device=dev, dtype=torch.bfloat16)
 h[:, :, :1200] = torch.randn(S, B, 1200, device=dev).relu_().bfloat16()
