@@ -107,6 +107,9 @@ SIGNATURES = {
                                              _i64, _int, _rngp, _rngp, _int, _int, ctypes.POINTER(KlTensor), _int, _p, _p]),
     "bnn_draw_multi": (_int, [ctypes.POINTER(DrawTensor), _int, _int, ctypes.POINTER(KlTensor), _int, _p, _p]),
     "bnn_dense_forward": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _int, _int, _p]),
+    "bnn_dense_head_parts": (_int, [_i64, _i64, _int]),
+    "bnn_dense_forward_head": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64,
+                                      _p, _i64, _i64, _i64, _int, _int, _p]),
     "bnn_dense_forward_x3": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64,
                                     _i64, _i64, _i64, _int, _int, _p]),
     "bnn_split_bf16x3": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p]),

@@ -18,6 +18,9 @@ class McContext:
         self.samples = samples
         self.base_batch = base_batch
         self.sample0 = sample0
+        # set by BayesianNetworkModule.predictive_mean: the caller reduces the outputs over the MC axis itself, so a hidden layer
+        # may fuse the classifier head behind it and hand on partial logits (ops.HeadPartials) instead of a tensor
+        self.lazy_head = False
 
     def __enter__(self):
         self.prev = getattr(_state, "ctx", None)

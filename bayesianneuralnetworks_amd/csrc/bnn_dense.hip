@@ -294,6 +294,16 @@ struct DenseParams {
     // stride in elements; 0 = plain bf16 operands
     int32_t x3;
     int64_t a_plane_stride, w_plane_stride, y_plane_stride;
+    // fused classifier head (bnn_dense_forward_head, YM = 3): the layer's output is NOT stored -- every consumer wave contracts
+    // its (16 TM) x (16 TN) tile of act(x w^T + b), rounded to bf16 as a stored hidden activation would be, with the matching
+    // columns of the head's drawn weights Wh (S x Nh x ldwh bf16, Nh <= 16) and stores the partial logits
+    //   P[part][s][m][j],  part = column panel * NWN + wave column  (ntn * NWN partials; partial 0 also carries the head's bias)
+    const uint16_t *Wh;
+    int64_t wh_sample_stride, ldwh;
+    const float *bias_h;
+    int64_t bias_h_sample_stride;
+    float *P;
+    int32_t Nh;
 };
 
 constexpr int kDenseNoXcdMap = 1 << 20;     // internal flag (BNN_DENSE_XCD=0): plain sample-major block order, for A/B runs
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     constexpr int B_STAGE = BN * 128;
     constexpr int STAGE = A_STAGE + B_STAGE;
     // epilogue staging (after the final barrier): EPI_A 16-row blocks of the wave's output tile at a time in its quarter of the ring
-    constexpr bool YBF = YM != 0;                       // YM: 0 fp32, 1 bf16, 2 three bf16 planes (h, m, l) of the fp32 result
+    constexpr bool YBF = YM != 0;                       // YM: 0 fp32, 1 bf16, 2 three bf16 planes (h, m, l) of the fp32 result, 3 fused head (no output)
     constexpr int ESZ = YBF ? 2 : 4;
     constexpr int EPI_BYTES = ST * STAGE / NWV;
     constexpr int EPI_A = (EPI_BYTES / (16 * WN * ESZ)) < TM ? (EPI_BYTES / (16 * WN * ESZ)) : TM;
@@ -363,9 +373,9 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     const int m0 = mt * BM, n0 = panel * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // x3: the six largest partial products of (xh + xm + xl)(wh + wm + wl), smallest first, as six 64-k steps per k-block on
-    // plane pairs (l, h) (h, l) (m, m) (m, h) (h, m) (h, h) -- the consumers see a plain GEMM of depth 6 K (dropped terms
-    // <= 2^-25 |x w|: below one fp32 rounding; same products and order as bnn_linear.hip's kComputeBf16x3)
+    // x3: the six largest partial products of (xh + xm + xl)(wh + wm + wl) as 64-k steps on plane pairs (l, h) (h, l) (m, m)
+    // (m, h) (h, m) -- those five for every k-block first -- and then (h, h) over all of K: the consumers see a plain GEMM of
+    // depth 6 K (dropped terms <= 2^-25 |x w|: below one fp32 rounding; the products of bnn_linear.hip's kComputeBf16x3)
     const int nk = (p.K + 63) / 64 * (p.x3 ? 6 : 1);
 
     if (wave >= NWV) {
@@ -406,8 +416,14 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
                 int kb = kt;
                 const char *ab = a_base, *wb = w_base;
                 if (p.x3) {
-                    kb = kt / 6;
-                    const int pr = kt - 6 * kb;
+                    // TWO sweeps over K: first the five small plane pairs (l,h) (h,l) (m,m) (m,h) (h,m) of every k-block, then
+                    // (h,h) over all of K.  The accumulator stays ~2^-8 of its final size through the first sweep, so the
+                    // 5 K / 32 fp32 roundings of the small terms are 2^-8 smaller than when they were interleaved with the
+                    // large products block by block (round 2: six pairs per k-block): max |fp32 mode - float64| on the
+                    // BASELINE net 1.36e-4 -> see DESIGN (the reference's own fp32 sgemm: 6.6e-5).  Same steps, same traffic.
+                    const int nkb = (p.K + 63) >> 6;
+                    int pr = 5;
+                    if (kt < 5 * nkb) { kb = kt / 5; pr = kt - 5 * kb; } else kb = kt - 5 * nkb;
                     ab += ((0x001102 >> (4 * pr)) & 3) * (p.a_plane_stride * 2);
                     wb += ((0x010120 >> (4 * pr)) & 3) * (p.w_plane_stride * 2);
                 }
@@ -550,6 +566,60 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     for (int b = 0; b < TN; ++b) {
         const int n = nw + b * 16 + fi;
         bv[b] = (bias && n < p.N) ? bias[n] : 0.f;
+    }
+    if constexpr (YM == 3) {
+        // ---- fused head: stage the wave's tile as bf16 rows (pitch 16 TN * 2 + 16 B: the 16 rows of a fragment read then hit
+        // 16 different bank groups), read it back as A fragments, one MFMA per (16-row block, 32 columns) against the head's
+        // weights for those hidden units (fragments straight from memory: Nh rows x 16 TN columns, read once per wave)
+        constexpr int pitch = WN * 2 + 16;
+        static_assert(WM * pitch <= EPI_BYTES, "the wave's quarter of the ring holds its bf16 tile");
+        char *T = lds + wave * EPI_BYTES;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[a][b][r] + bv[b];
+                    if (RELU) v = fmaxf(v, 0.f);
+                    *reinterpret_cast<uint16_t *>(T + (a * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * 2) = f2bf(v);
+                }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int Nh = p.Nh;
+        const int hrow = fi < Nh ? fi : Nh - 1;
+        const uint16_t *wh = p.Wh + (int64_t)s * p.wh_sample_stride + (int64_t)hrow * p.ldwh;
+        f32x4 hacc[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) hacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NC = (WN + 31) / 32;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int kcol = 32 * c + 8 * fq;              // column of the wave tile
+            const int n = nw + kcol;                       // hidden unit
+            // hidden units >= N: the weight rows of THIS layer were clamped there (duplicates of row N - 1), so the head's
+            // weights must be zero: they are, up to their row pitch (zero padding of the draw); beyond it nothing is read
+            uint4 bf = make_uint4(0u, 0u, 0u, 0u);
+            if (kcol < WN && fi < Nh && n + 8 <= (int)p.ldwh) bf = *reinterpret_cast<const uint4 *>(wh + n);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                uint4 af = make_uint4(0u, 0u, 0u, 0u);
+                if (kcol < WN) af = *reinterpret_cast<const uint4 *>(T + (a * 16 + fi) * pitch + kcol * 2);
+                hacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), hacc[a], 0, 0, 0);
+            }
+        }
+        const int part = panel * NWN + wn;
+        float hb = 0.f;
+        if (part == 0 && p.bias_h && fi < Nh) hb = p.bias_h[(int64_t)s * p.bias_h_sample_stride + fi];
+        float *P = p.P + ((int64_t)part * p.S + s) * (int64_t)p.M * Nh;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mw + a * 16 + fq * 4 + r;
+                if (m < p.M && fi < Nh) P[(int64_t)m * Nh + fi] = hacc[a][r] + hb;
+            }
+        return;
     }
     // plane pl of the result: bf16(v), bf16(v - h), bf16(v - h - m) -- the split of split_bf16x3 (residuals exact in fp32)
     auto plane_of = [&](float v, int pl) -> uint16_t {
@@ -998,13 +1068,39 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float *__restrict__ 
 }
 }  // namespace bnn
 
+// the fused head's operands (dense_launch's `head`, NULL = the plain layer)
+struct HeadArgs {
+    const void *wh;
+    int64_t wh_sample_stride, ldwh;
+    const float *bh;
+    int64_t bh_sample_stride;
+    float *partials;
+    int64_t nh;
+};
+
+// tile of a dense launch: 0 (256 x 80), 1 (128 x 160), 2 (256 x 128), 3 (64 x 160), 4 (32 x 160) -- see dense_launch
+static int dense_pick_tile(int64_t M, int64_t N, int nsamples)
+{
+    static const int force_tile = [] { const char *e = getenv("BNN_DENSE_TILE"); return e ? atoi(e) : -1; }();
+    int tile = (N % 80 == 0 || N < 128) ? 1 : 2;
+    if (N <= 80) tile = 0;
+    if (force_tile >= 0 && force_tile <= 4) tile = force_tile;
+    if (tile == 1 && force_tile < 0) {
+        const int64_t cols = (N + 159) / 160;
+        if (((M + 127) / 128) * cols * nsamples < 128 && M > 64) tile = 3;
+        if (tile == 3 && ((M + 63) / 64) * cols * nsamples < 128 && M > 32) tile = 4;
+    }
+    return tile;
+}
+
 static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,
                         const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
                         const float *b, int64_t b_sample_stride,
                         void *y, int64_t y_plane_stride, int64_t y_sample_stride, int64_t ldy,
-                        int64_t M, int64_t N, int64_t K, int nsamples, int flags, bool x3, void *stream)
+                        int64_t M, int64_t N, int64_t K, int nsamples, int flags, bool x3, void *stream, const HeadArgs *head = nullptr)
 {
     if (M == 0 && N >= 1 && K >= 1 && nsamples >= 1) return BNN_OK;
+    if (head) { y = head->partials; ldy = N; }           // (no output tensor: the checks below see the partials)
     if (!x || !w || !y) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (M < 0 || N < 1 || K < 1 || nsamples < 1 || ldx < K || ldy < N) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
     if (M > 0x7FFFFFFF || N > 0x7FFFFFFF || K > 0x7FFFFFFF) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
@@ -1032,6 +1128,18 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
         p.x3 = 1;
         p.a_plane_stride = x_plane_stride; p.w_plane_stride = w_plane_stride; p.y_plane_stride = y_plane_stride;
     }
+    if (head) {
+        if (x3 || N <= 16 || (flags & BNN_FLAG_Y_BF16) == 0) { set_error("%s: the fused head follows a bf16 hidden layer wider than 16", who); return BNN_E_UNSUPPORTED; }
+        if (!head->wh || head->nh < 1 || head->nh > 16) { set_error("%s: head of 1 .. 16 outputs", who); return BNN_E_SHAPE; }
+        if (N % 8 != 0 || head->ldwh % 8 != 0 || head->ldwh < N || head->wh_sample_stride % 8 != 0 || !al16(head->wh) ||
+            (reinterpret_cast<uintptr_t>(head->partials) & 3u)) {
+            set_error("%s: the head's weights need N %% 8 == 0 and 16-B aligned rows zero-padded to ldwh >= N", who);
+            return BNN_E_UNSUPPORTED;
+        }
+        p.Wh = reinterpret_cast<const uint16_t *>(head->wh); p.wh_sample_stride = head->wh_sample_stride; p.ldwh = head->ldwh;
+        p.bias_h = head->bh; p.bias_h_sample_stride = head->bh_sample_stride;
+        p.P = head->partials; p.Nh = (int32_t)head->nh;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (N <= 16 && K <= 4 * kHeadMaxSteps * 32) {
         p.ntm = (int32_t)((M + 15) / 16);
@@ -1044,20 +1152,12 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
     // tile: the BASELINE-shaped layers (N % 80 == 0: 1200 = 7.5 x 160) take 128 x 160 with a 4-stage ring -- 36 KiB per
     // 64-k step instead of 256 x 80's 42 for the same MFMAs, 4 x 8 x 8 = 256 workgroups; wide layers 256 x 128.
     // BNN_DENSE_TILE = 0 (256 x 80), 1 (128 x 160), 2 (256 x 128), 3 (64 x 160), 4 (32 x 160) forces one for A/B runs.
-    static const int force_tile = [] { const char *e = getenv("BNN_DENSE_TILE"); return e ? atoi(e) : -1; }();
-    int tile = (N % 80 == 0 || N < 128) ? 1 : 2;
-    if (N <= 80) tile = 0;
-    if (force_tile >= 0 && force_tile <= 4) tile = force_tile;
+    const int tile = dense_pick_tile(M, N, nsamples);
     // few samples (a rank of a sharded MC job runs 8 / G of them): 64- and 32-row versions of the 128 x 160 tile, the largest
     // that still gives >= 128 workgroups -- a dense launch over ONE sample (32 workgroups) took as long as over eight.
     // Measured at the BASELINE layers, one stream / three steps in flight, us per step: 4 samples 54.2 / 28.3 (128 rows),
     // 51.0 / 30.9 (64), 58.7 / 37.4 (32); 2 samples 48.8 / 22.3, 44.3 / 20.8, 41.9 / 24.0; 1 sample 46.2 / 19.3, 41.3 / 17.8,
     // 39.0 / 17.9: with the chip already full of other steps' work the bigger tile wins (fewer re-reads of the weights).
-    if (tile == 1 && force_tile < 0) {
-        const int64_t cols = (N + 159) / 160;
-        if (((M + 127) / 128) * cols * nsamples < 128 && M > 64) tile = 3;
-        if (tile == 3 && ((M + 63) / 64) * cols * nsamples < 128 && M > 32) tile = 4;
-    }
     const int bm = tile == 1 ? 128 : tile == 3 ? 64 : tile == 4 ? 32 : 256;
     const int bn = tile == 0 ? 80 : tile == 2 ? 128 : 160;
     p.ntm = (int32_t)((M + bm - 1) / bm);
@@ -1069,7 +1169,8 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
     const dim3 g((unsigned)grid), blk(512);
 #define BNN_DENSE_LAUNCH(TM_, TN_, NWM_, NWN_, ST_, RELU_) \
     do { \
-        if (x3 && ybf) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 2, RELU_>), g, blk, 0, st, p); \
+        if (head) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 3, RELU_>), g, blk, 0, st, p); \
+        else if (x3 && ybf) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 2, RELU_>), g, blk, 0, st, p); \
         else if (!ybf) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 0, RELU_>), g, blk, 0, st, p); \
         else if (diag == 1) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 1>), g, blk, 0, st, p); \
         else if (diag == 2) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 2>), g, blk, 0, st, p); \
@@ -1168,6 +1269,27 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
 {
     return dense_launch("bnn_dense_forward", x, 0, x_sample_stride, ldx, w, 0, w_sample_stride, ldw, b, b_sample_stride,
                         y, 0, y_sample_stride, ldy, M, N, K, nsamples, flags, false, stream);
+}
+
+int bnn_dense_head_parts(int64_t M, int64_t N, int nsamples)
+{
+    if (M < 1 || N < 17 || nsamples < 1) return 0;
+    const int tile = dense_pick_tile(M, N, nsamples);
+    const int bn = tile == 0 ? 80 : tile == 2 ? 128 : 160;
+    const int nwn = (tile == 0 || tile == 2) ? 1 : 2;
+    return (int)((N + bn - 1) / bn) * nwn;
+}
+
+int bnn_dense_forward_head(const void *x, int64_t x_sample_stride, int64_t ldx,
+                           const void *w, int64_t w_sample_stride, int64_t ldw,
+                           const float *b, int64_t b_sample_stride,
+                           const void *w_head, int64_t wh_sample_stride, int64_t ldwh,
+                           const float *b_head, int64_t bh_sample_stride, int64_t n_head,
+                           float *partials, int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream)
+{
+    HeadArgs h{w_head, wh_sample_stride, ldwh, b_head, bh_sample_stride, partials, n_head};
+    return dense_launch("bnn_dense_forward_head", x, 0, x_sample_stride, ldx, w, 0, w_sample_stride, ldw, b, b_sample_stride,
+                        nullptr, 0, 0, N, M, N, K, nsamples, flags | BNN_FLAG_Y_BF16, false, stream, &h);
 }
 
 int bnn_dense_forward_x3(const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(kMcThreads) void k_mc_sum(const float *__restrict__
                                                        uint32_t *advance_epoch, uint32_t advance_inc)
 {
     if (advance_epoch && blockIdx.x == 0 && threadIdx.x == 0) advance_epoch[0] += advance_inc;   // nothing in this kernel draws
-    mc_sum_body(y, y_sample_stride, nsamples, n, scale, out, accumulate, (int)blockIdx.x, (int)gridDim.x);
+    if (nsamples > kMcSplitAbove) mc_sum_split_body(y, y_sample_stride, nsamples, n, scale, out, accumulate, (int)blockIdx.x);
+    else mc_sum_body(y, y_sample_stride, nsamples, n, scale, out, accumulate, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------- diagnostics
@@ -405,7 +406,12 @@ int bnn_mc_sum(const float *y, int64_t y_sample_stride, int nsamples, int64_t n,
     if (!y || !out) { set_error("bnn_mc_sum: NULL pointer"); return BNN_E_NULL; }
     if (n < 0 || nsamples < 1) { set_error("bnn_mc_sum: bad extent"); return BNN_E_SHAPE; }
     if (n == 0) return advance_epoch ? bnn_rng_advance(advance_epoch, advance_inc, stream) : BNN_OK;
-    hipLaunchKernelGGL(k_mc_sum, dim3(grid_for(n)), dim3(kMcThreads), 0, (hipStream_t)stream, y, y_sample_stride,
+    unsigned grid = grid_for(n);
+    if (nsamples > kMcSplitAbove) {
+        if (nsamples > 4 * kMcSplitMax || (n + 63) / 64 > 0x7FFFFFF0) { set_error("bnn_mc_sum: more than %d addends per output (or too many outputs)", 4 * kMcSplitMax); return BNN_E_RANGE; }
+        grid = (unsigned)((n + 63) / 64);
+    }
+    hipLaunchKernelGGL(k_mc_sum, dim3(grid), dim3(kMcThreads), 0, (hipStream_t)stream, y, y_sample_stride,
                        nsamples, n, scale, out, accumulate, advance_epoch, advance_inc);
     return check_launch("bnn_mc_sum");
 }

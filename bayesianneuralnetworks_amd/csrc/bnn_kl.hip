@@ -70,7 +70,8 @@ __global__ __launch_bounds__(kKlThreads) void k_mc_sum_kl(const float *__restric
         return;
     }
     if (advance_epoch && blockIdx.x == 0 && threadIdx.x == 0) advance_epoch[0] += advance_inc;
-    mc_sum_body(y, y_sample_stride, nsamples, n, scale, out, accumulate, (int)blockIdx.x, nmc);
+    if (nsamples > kMcSplitAbove) mc_sum_split_body(y, y_sample_stride, nsamples, n, scale, out, accumulate, (int)blockIdx.x);   // (uniform)
+    else mc_sum_body(y, y_sample_stride, nsamples, n, scale, out, accumulate, (int)blockIdx.x, nmc);
 }
 
 __global__ __launch_bounds__(kKlThreads) void k_kl_backward(KlLaunch L, const float *__restrict__ upstream,
@@ -252,6 +253,11 @@ int bnn_mc_sum_kl(const float *y, int64_t y_sample_stride, int nsamples, int64_t
     kl_first_pass(tensors, ntensors, nullptr, nullptr, F, false, "bnn_mc_sum_kl");
     int64_t b = (n + kMcThreads - 1) / kMcThreads;
     if (b > 2048) b = 2048;
+    if (nsamples > kMcSplitAbove) {
+        if (nsamples > 4 * kMcSplitMax) { set_error("bnn_mc_sum_kl: more than %d addends per output", 4 * kMcSplitMax); return BNN_E_RANGE; }
+        b = (n + 63) / 64;
+        if (b > 0x7FFFFFF0) { set_error("bnn_mc_sum_kl: too many outputs"); return BNN_E_RANGE; }
+    }
     hipLaunchKernelGGL(k_mc_sum_kl, dim3((unsigned)b + 1), dim3(kKlThreads), 0, (hipStream_t)stream, y, y_sample_stride, nsamples, n,
                        scale, out, accumulate, advance_epoch, advance_inc, F, reinterpret_cast<const double *>(workspace), kl_out);
     return check_launch("bnn_mc_sum_kl");

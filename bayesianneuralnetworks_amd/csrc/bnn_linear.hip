@@ -387,6 +387,17 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bf16x3: the five SMALL partial products (each <= 2^-8 of the (h,h) one) go to an accumulator of their own and are added
+    // once, at the end -- interleaved into the large sum they cost it five fp32 roundings at full magnitude per 32 k instead
+    // of one (the dense path's two sweeps over K, bnn_dense.hip, to the same end; 4 TM TN more VGPRs here, where the wave
+    // tile is small)
+    f32x4 acc_s[X3 ? TM : 1][X3 ? TN : 1];
+    if constexpr (X3) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc_s[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     auto mfma_step = [&](int stage, const uint4 *Bs) {
         const uint4 *As = Aw + stage * A_STAGE;
@@ -439,14 +450,14 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
                 for (int a = 0; a < TM; ++a) {
                     const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[a]), xm = __builtin_bit_cast(bf16x8, am[a]),
                                  xl = __builtin_bit_cast(bf16x8, al[a]);
-                    f32x4 c = acc[a][b];
+                    f32x4 c = acc_s[a][b];
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bm, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, bh, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bm, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, c, 0, 0, 0);
-                    acc[a][b] = c;
+                    acc_s[a][b] = c;
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, acc[a][b], 0, 0, 0);
                 }
             }
         } else {
@@ -617,6 +628,12 @@ __global__ __launch_bounds__(NW * 64) void k_linear_sym(const GemmParams p)
     // nothing may still be writing this workgroup's LDS when it retires
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(12);                                                      // loop done
+    if constexpr (X3) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] += acc_s[a][b];
+    }
 
     // a hand-off wait that gave up has consumed an undrawn chunk or drawn into a busy buffer: the device error word is
     // set (bnn_check_device reports it) and this wave's results are not stored

@@ -31,4 +31,35 @@ __device__ __forceinline__ void mc_sum_body(const float *__restrict__ y, int64_t
     }
 }
 
+// The same reduction for MANY addends per output (a fused head's ntn * NWN * S partial logits: 128 at the BASELINE layer): a
+// workgroup takes 64 outputs, its four waves a quarter of the addends each -- every load of a wave's quarter is requested before
+// the first add (one memory round trip instead of nsamples / 8) -- and the four sums are added in wave order through LDS:
+// fixed order, bitwise reproducible.  Launch with ceil(n / 64) workgroups of 256 threads.
+constexpr int kMcSplitAbove = 32;       // addends per output from which the launchers take this body
+constexpr int kMcSplitMax = 64;         // addends per wave held in registers: nsamples <= 4 * 64
+
+__device__ __forceinline__ void mc_sum_split_body(const float *__restrict__ y, int64_t y_sample_stride, int nsamples, int64_t n,
+                                                  float scale, float *__restrict__ out, int accumulate, int block)
+{
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)block * 64 + lane;
+    const int per = (nsamples + 3) >> 2;
+    const int s0 = grp * per, s1 = s0 + per < nsamples ? s0 + per : nsamples;
+    float a = 0.f;
+    if (i < n) {
+        float v[kMcSplitMax];
+#pragma unroll
+        for (int j = 0; j < kMcSplitMax; ++j) v[j] = (s0 + j < s1) ? y[(int64_t)(s0 + j) * y_sample_stride + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < kMcSplitMax; ++j) a += v[j];
+    }
+    part[grp][lane] = a;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        const float t = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) * scale;
+        out[i] = accumulate ? out[i] + t : t;
+    }
+}
+
 }  // namespace bnn

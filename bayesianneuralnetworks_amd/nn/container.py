@@ -77,9 +77,28 @@ class BayesianNetworkModule(Module):
         (views of one (S*B, ...) tensor)."""
         return list(self._forward_batched_stacked(x, samples, sample0, *args, **kwargs).unbind(0))
 
-    def _forward_batched_stacked(self, x, samples, sample0, *args, **kwargs):
+    def predictive_mean(self, x, samples=None, sample0=0, out=None, scale=None, advance=None, kl=None, *args, **kwargs):
+        """scale (default 1 / samples) * sum over the MC samples of `_forward(x)` -- torch.stack(preds).mean(0) of
+        examples/MNIST/uncertainty.py:50 -- as the tail of ONE batched pass: the caller wants the mean, not the samples, so a
+        hidden layer may run fused with the classifier head behind it (nn.fuse_activations; bnn_dense_forward_head) and the
+        reduction adds that pair's partial logits in the same launch.  out / advance / kl: as ops.mc_mean."""
+        from .. import ops
+        if samples is None:
+            samples = self.samples
+        if not (self.mc_batched and isinstance(x, torch.Tensor) and x.is_cuda):
+            ys = self.forward_stacked(x, samples, sample0, *args, **kwargs)
+            m = ys.sum(0) * ((1.0 / samples) if scale is None else scale)
+            if out is not None:
+                out.copy_(m.reshape(out.shape))
+                return out
+            return m
+        y = self._forward_batched_stacked(x, samples, sample0, *args, _lazy_head=True, **kwargs)
+        return ops.mc_mean(y, out=out, scale=(1.0 / samples) if scale is None else scale, advance=advance, kl=kl)
+
+    def _forward_batched_stacked(self, x, samples, sample0, *args, _lazy_head=False, **kwargs):
         B = x.shape[0]
         with _mc.McContext(samples, B, sample0) as ctx:
+            ctx.lazy_head = _lazy_head
             drawn = self._draw_plan(ctx)
             try:
                 y = self._forward(x, *args, **kwargs)
@@ -89,6 +108,9 @@ class BayesianNetworkModule(Module):
                     if left is not None:
                         left[1].wait()          # a layer `_forward` never reached: join its side-stream draw anyway
                     m._predrawn = None
+        from .. import ops
+        if isinstance(y, ops.HeadPartials):
+            return y if _lazy_head else y.logits()
         if y.shape[0] == B * samples:
             return y.view(samples, B, *y.shape[1:])
         if y.shape[0] == B:

@@ -125,6 +125,33 @@ class _NormalSampling:
         x2 = x if isinstance(x, ops.X3Activation) else x
         return ops.x3_eligible(x2, self.weight.mean, rows)
 
+    def _try_fused_head(self, x2, shared, per, S, mode, predrawn, sample_head):
+        """This hidden layer + the classifier head behind it in ONE launch (bnn_dense_forward_head)?  Only when the caller has
+        said it will reduce the outputs itself (predictive_mean -> McContext.lazy_head), in the bf16 mode, at inference, with
+        both layers' weights drawn by the network's plan for THIS forward -- otherwise None (the plain path runs)."""
+        ctx = _mc.current()
+        head = self.__dict__.get("_fuse_head")
+        if head is None or ctx is None or not ctx.lazy_head or mode != "bf16" or predrawn is None or torch.is_grad_enabled():
+            return None
+        hd = getattr(head, "_predrawn", None)
+        if hd is None or hd[0] is not ctx or self.out_dtype != torch.bfloat16 or head._compute_mode() != "bf16" or head.activation is not None:
+            return None
+        K = x2.shape[-1]
+        if not ops.dense_head_eligible(per, self.weight.mean.shape[0], predrawn, hd[1]) or predrawn.w.dim() != 3:
+            return None
+        if x2.dtype == torch.bfloat16:
+            pitch = ops.rows_pitch(x2, K)
+            xb, ldx, xs = (x2, pitch[0], pitch[1]) if pitch is not None else (x2.contiguous(), K, per * K)
+        else:
+            xb, ldx, xs = x2.contiguous().to(torch.bfloat16), K, per * K
+        head._predrawn = None                                   # the head's drawn weights are consumed here ...
+        head._adopt_keys(hd[1].key_w, hd[1].key_b)              # ... and this is its sample() for this forward
+        predrawn.wait()
+        hd[1].wait()
+        hp = ops._dense_head_raw(xb, 0 if shared else xs, per, predrawn, K, self.activation == 'relu', hd[1], ldx=ldx)
+        hp.head = head
+        return hp
+
     def _keys(self, S):
         kw = self.weight.draw_key
         kb = self.bias.draw_key if self.bias is not None else None
@@ -155,6 +182,12 @@ class NormalLinear(_NormalSampling, BayesianLinear):
                 self.sample()
             y = torch.nn.functional.linear(x, *self.sampled)
             return torch.relu(y) if self.activation == 'relu' else y
+        if isinstance(x, ops.HeadPartials):
+            # the hidden layer in front of this head contracted with this layer's drawn weights in its own launch
+            # (ops._dense_head_raw): nothing left to do here but pass the partial logits on
+            if x.head is not self:
+                raise RuntimeError("a fused hidden layer's partial logits reached a layer that is not its head")
+            return x
         if x.dim() == 1:
             return self.forward(x.unsqueeze(0), sample).squeeze(0)
         # weights already drawn for this forward by the network's draw plan (container._draw_plan)?  Consumed on use.
@@ -189,6 +222,9 @@ class NormalLinear(_NormalSampling, BayesianLinear):
         x2 = x.reshape(-1, K) if shared else x.reshape(S, -1, K)
         if keys is not None:
             odt = torch.bfloat16 if (self.out_dtype == torch.bfloat16 and mode == "bf16") else torch.float32
+            hp = self._try_fused_head(x2, shared, per, S, mode, predrawn, sample_head=True)
+            if hp is not None:
+                return hp
             y = ops.linear_sampled(x2, self.weight.mean, self.weight.scale,
                                    self.bias.mean if self.bias is not None else None,
                                    self.bias.scale if self.bias is not None else None,

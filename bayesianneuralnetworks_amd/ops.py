@@ -275,6 +275,61 @@ def _dense_raw(x2, x_sample_stride, M, pre, K, relu, out_dtype, ldx=None, pad_ro
     return ybuf if ldy == N else ybuf[:, :, :N]
 
 
+class HeadPartials:
+    """What a hidden layer fused with the classifier head behind it leaves (bnn_dense_forward_head): PARTIAL logits
+    (parts, S, M, Nh) fp32 -- the head's contraction cut along the hidden units, partial 0 carrying the head's bias.  Not a
+    tensor: the head layer passes it through, `BayesianNetworkModule.predictive_mean` / `ops.mc_mean` reduce it over
+    (part, sample) in the step's ONE tail launch, `.logits()` over `part` for callers that want every sample."""
+    __slots__ = ("p", "head")
+
+    def __init__(self, p, head=None):
+        self.p, self.head = p, head
+
+    @property
+    def shape(self):
+        return torch.Size((self.p.shape[1] * self.p.shape[2], self.p.shape[3]))
+
+    @property
+    def is_cuda(self):
+        return True
+
+    @property
+    def device(self):
+        return self.p.device
+
+    def dim(self):
+        return 2
+
+    def logits(self):
+        """(S, M, Nh): the sum over the partials (one bnn_mc_sum launch)."""
+        parts, S, M, Nh = self.p.shape
+        out = torch.empty((S, M, Nh), dtype=torch.float32, device=self.p.device)
+        n = S * M * Nh
+        check(_lib.load().bnn_mc_sum(ptr(self.p), n, parts, n, 1.0, ptr(out), 0, None, 0, stream_ptr(self.p.device)), "bnn_mc_sum")
+        return out
+
+
+def dense_head_eligible(M, N, pre, pre_head):
+    """Hidden layer (drawn weights `pre`, N > 16 outputs) + head (`pre_head`, <= 16 outputs) in one launch?"""
+    return (pre is not None and pre_head is not None and pre.w.dim() == 3 and pre_head.w.dim() == 3 and N > 16 and N % 8 == 0 and
+            pre_head.w.shape[1] <= 16 and pre_head.w.shape[2] >= N and pre.w.shape[0] == pre_head.w.shape[0] and M > 0)
+
+
+def _dense_head_raw(x2, x_sample_stride, M, pre, K, relu, pre_head, ldx=None):
+    """bnn_dense_forward_head: act(x . w_s^T + b_s) rounded to bf16 and contracted with the head's drawn weights in the same
+    launch -> HeadPartials (the hidden activation is never stored)."""
+    S, N, kp = pre.w.shape
+    _, Nh, kph = pre_head.w.shape
+    lib = _lib.load()
+    parts = lib.bnn_dense_head_parts(M, N, S)
+    P = torch.empty((parts, S, M, Nh), dtype=torch.float32, device=x2.device)
+    ldx = K if ldx is None else ldx
+    check(lib.bnn_dense_forward_head(ptr(x2), x_sample_stride, ldx, ptr(pre.w), N * kp, kp, ptr(pre.b), N if pre.b is not None else 0,
+                                     ptr(pre_head.w), Nh * kph, kph, ptr(pre_head.b), Nh if pre_head.b is not None else 0, Nh,
+                                     ptr(P), M, N, K, S, _lib.FLAG_RELU if relu else 0, stream_ptr(x2.device)), "bnn_dense_forward_head")
+    return HeadPartials(P)
+
+
 class X3Activation:
     """A hidden activation of the fp32 parity mode as it travels between two dense layers: the fp32 values as three bf16
     planes (3, S, M, ld) (h, m, l: v = h + m + l to 2^-24 |v|), `cols` valid columns.  Not a tensor: only NormalLinear
@@ -1196,12 +1251,20 @@ def mc_mean(y, out=None, scale=None, advance=None, kl=None):
     examples/MNIST/uncertainty.py:50).  `out` (optional, y[0].numel() floats) is written in place.
     `advance` (optional, a device epoch cell of _rng.EpsGenerator.epoch_dev) is bumped by one in the
     same launch: the fresh-noise step of a captured MC forward without a launch of its own.
-    `kl` (optional, a KlDeferred from kl_normal_begin): that KL's second pass runs in this launch too."""
+    `kl` (optional, a KlDeferred from kl_normal_begin): that KL's second pass runs in this launch too.
+    y may be a HeadPartials (a hidden layer fused with its classifier head): the same launch then adds the partial logits over
+    (part, sample) -- the default scale stays 1 / S."""
+    if isinstance(y, HeadPartials):
+        parts, S, M, Nh = y.p.shape
+        y = y.p.view(parts * S, M, Nh)              # addend v = part * S + s, M * Nh floats apart
+        nadd, out_shape = parts * S, (M, Nh)
+    else:
+        S = nadd = y.shape[0]
+        out_shape = y.shape[1:]
     require_cuda_f32(y, "y")
-    S = y.shape[0]
     n = y[0].numel()
     if out is None:
-        out = torch.empty(y.shape[1:], dtype=torch.float32, device=y.device)
+        out = torch.empty(out_shape, dtype=torch.float32, device=y.device)
     else:
         require_cuda_f32(out, "out")
         if out.numel() != n:
@@ -1217,11 +1280,11 @@ def mc_mean(y, out=None, scale=None, advance=None, kl=None):
                 _tls.kl_carry = None
             check(_lib.load().bnn_kl_forward_partial(kl.arr, kl.T, ptr(kl.ws), stream_ptr(y.device)), "bnn_kl_forward_partial")
             kl.launched = True
-        check(_lib.load().bnn_mc_sum_kl(ptr(y), n, S, n, sc, ptr(out), 0, adv, 1, kl.arr, kl.T, kl.n_batches,
+        check(_lib.load().bnn_mc_sum_kl(ptr(y), n, nadd, n, sc, ptr(out), 0, adv, 1, kl.arr, kl.T, kl.n_batches,
                                         ptr(kl.out), ptr(kl.ws), stream_ptr(y.device)), "bnn_mc_sum_kl")
         kl.done = True
         return out
-    check(_lib.load().bnn_mc_sum(ptr(y), n, S, n, sc, ptr(out), 0, adv, 1, stream_ptr(y.device)), "bnn_mc_sum")
+    check(_lib.load().bnn_mc_sum(ptr(y), n, nadd, n, sc, ptr(out), 0, adv, 1, stream_ptr(y.device)), "bnn_mc_sum")
     return out
 
 

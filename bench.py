@@ -128,13 +128,17 @@ class Step:
     second queue costs more in cross-queue dependency latency than it hides).  KL sums and the sum of
     predictions land directly in the packed buffer that the one collective all-reduces."""
 
-    def __init__(self, net, x, rank, world, use_graph, samples=SAMPLES, sample0=None, total_samples=None, private=False):
+    def __init__(self, net, x, rank, world, use_graph, samples=SAMPLES, sample0=None, total_samples=None, private=False,
+                 fuse_head=None):
         from bayesianneuralnetworks_amd import ops, _lib, distributed as bd
         from bayesianneuralnetworks_amd._rng import default_generator
         self.net, self.x, self.rank, self.world = net, x, rank, world
         # private: this step's launches read and bump an epoch word (and use a KL workspace) of their own, so that it can be
         # replayed concurrently with another step on another stream (PipelinedSteps)
         self.private = private
+        # fuse_head (default: on, BNN_BENCH_FUSE_HEAD=0 switches it off): layer 2 and the classifier head as ONE launch -- the
+        # step asks for the predictive mean, not for the samples (net.predictive_mean) -- four launches per step instead of five
+        self.fuse_head = (os.environ.get("BNN_BENCH_FUSE_HEAD", "1") != "0") if fuse_head is None else bool(fuse_head)
         self.cell = None
         self.samples = samples
         self.sample0 = rank * samples if sample0 is None else sample0
@@ -213,10 +217,14 @@ class Step:
             if mode == "serial":
                 self._kl()
             kl_h = self._kl_begin(mode == "carry") if mode in ("tail", "carry") else None
-            ys = self.net.forward_stacked(self.x, self.samples, sample0=self.sample0)   # (S, B, 10)
             # fresh noise on every replay: the reduction also bumps the device epoch (last kernel of the step)
-            self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / self.total,
-                             advance=self.gen.epoch_dev(dev), kl=kl_h)        # (the private cell while one is installed)
+            if self.fuse_head:
+                self.net.predictive_mean(self.x, self.samples, sample0=self.sample0, out=self.packed[self.T + 1:],
+                                         scale=1.0 / self.total, advance=self.gen.epoch_dev(dev), kl=kl_h)
+            else:
+                ys = self.net.forward_stacked(self.x, self.samples, sample0=self.sample0)   # (S, B, 10)
+                self.ops.mc_mean(ys, out=self.packed[self.T + 1:], scale=1.0 / self.total,
+                                 advance=self.gen.epoch_dev(dev), kl=kl_h)        # (the private cell while one is installed)
             if kl_h is not None and self.world > 1:
                 self._kl_scatter()
         return self.packed

@@ -261,6 +261,24 @@ int bnn_dense_forward(const void *x, int64_t x_sample_stride, int64_t ldx,
                       const float *b, int64_t b_sample_stride,
                       void *y, int64_t y_sample_stride, int64_t ldy,
                       int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream);
+/* A hidden layer AND the classifier head behind it in ONE launch (bf16 compute mode, inference): the hidden layer's output
+ * act(x[s] w[s]^T + b[s]) is never stored -- every wave of the GEMM rounds its tile to bf16 (exactly what a stored bf16 hidden
+ * activation holds) and contracts it with the matching columns of the head's drawn weights w_head (S x n_head x ldwh bf16, rows
+ * zero beyond N up to ldwh, n_head <= 16), leaving PARTIAL logits
+ *     partials[part][s][m][j],  part < bnn_dense_head_parts(M, N, nsamples),  fp32, M x n_head per (part, s);
+ * partial 0 also carries the head's bias b_head (S x n_head fp32 or NULL).  The logits of sample s are the sum over `part`
+ * (bnn_mc_sum with nsamples = parts, y_sample_stride = S * M * n_head, n = S * M * n_head), the predictive mean the sum over
+ * (part, s) scaled by 1 / S (bnn_mc_sum / bnn_mc_sum_kl with nsamples = parts * S, y_sample_stride = M * n_head): one launch
+ * (the head's own, >= 4 us) and the hidden activation's S * M * N * 2 bytes of stores fewer per forward.  Same bf16 products as
+ * bnn_dense_forward twice; fp32 sums in another (fixed) order.
+ * replaces  two consecutive F.linear(x, *self.sampled)  pytorch_bayesian/nn/dense.py:60 (+ the ReLU between them) */
+int bnn_dense_head_parts(int64_t M, int64_t N, int nsamples);
+int bnn_dense_forward_head(const void *x, int64_t x_sample_stride, int64_t ldx,
+                           const void *w, int64_t w_sample_stride, int64_t ldw,
+                           const float *b, int64_t b_sample_stride,
+                           const void *w_head, int64_t wh_sample_stride, int64_t ldwh,
+                           const float *b_head, int64_t bh_sample_stride, int64_t n_head,
+                           float *partials, int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream);
 /* The same layer in the fp32 PARITY mode (1e-5 against the reference) on the same kernel: x and w are BNN_BF16X3 operands
  * (plane p at + p * plane_stride elements; x from bnn_split_bf16x3 or a previous layer's BNN_FLAG_Y_BF16 output, w from
  * bnn_draw_multi with out_dtype BNN_BF16X3) and the contraction runs the six largest partial products of
@@ -488,7 +506,8 @@ int bnn_prune_score(const float *mu, const float *rho, float *out, int64_t n, vo
 
 /* ---- MC reduction ----------------------------------------------------------
  * replaces  torch.stack(preds).mean(0)   examples/MNIST/uncertainty.py:50
- *   out[i] (+)= scale * sum_s y[s * y_sample_stride + i],  i < n.
+ *   out[i] (+)= scale * sum_s y[s * y_sample_stride + i],  i < n   (nsamples <= 256; more than 32 addends per output -- the
+ *   partial logits of bnn_dense_forward_head -- are summed by four waves per 64 outputs, fixed order).
  * advance_epoch (may be NULL): advance_epoch[0] += advance_inc in the same launch -- the
  * reduction is the tail of an MC step (every draw of the step has been consumed by the
  * kernels stream-ordered before it), so this saves the separate bnn_rng_advance launch. */

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import allclose_scaled
+from conftest import allclose_scaled, assert_close_scaled
 import seeded
 
 pytestmark = pytest.mark.gpu
@@ -313,13 +313,26 @@ def test_conv_dense_path_vs_oracle(env, B, C, O, H, W, k, st, pad, dil, shared):
     ew = orc.eps_fill(kw.seed, kw.stream, kw.sample0, kw.epoch_host, 0, tuple(layer.weight.shape), kw.gen)
     w_or = orc.sample_affine(N(layer.weight.mean), N(layer.weight.scale), ew)
     assert (np.abs(N(wt[0]) - w_or) <= np.abs(w_or) * 2.0 ** -8 + 1e-6).all()
-    nb = min(B, 6)                                              # images checked per sample (first and last ones)
+    nb = min(B, 6)                                              # images the SCALAR oracle checks per sample (first and last ones)
     sel = sorted(set(list(range(nb // 2)) + list(range(B - (nb - nb // 2), B))))
     xr = orc.bf16_round(x.numpy())
     for s in range(S):
         xs = xr[sel] if shared else xr[s * B:(s + 1) * B][sel]
         want = orc.conv2d(xs, N(wt[s]), N(pre.b[s]), stride=(st, st), padding=(pad, pad), dilation=(dil, dil))
         assert allclose_scaled(y[s][sel], want), np.abs(y[s][sel] - want).max()
+    # EVERY image of EVERY workgroup tile (the slice above leaves most tiles of configs[2] / [3] unseen): the whole
+    # batch against torch's conv2d in float64 on the CPU, fed the device's own bf16 weights and the bf16-rounded inputs --
+    # pinned to the scalar oracle on the slice just checked
+    xr64 = torch.from_numpy(xr).double()
+    worst = 0.0
+    for s in range(S):
+        xs = xr64 if shared else xr64[s * B:(s + 1) * B]
+        full = torch.nn.functional.conv2d(xs, wt[s].double().cpu(), pre.b[s].double().cpu(), stride=st, padding=pad, dilation=dil).numpy()
+        assert np.abs(full[sel] - orc.conv2d(xs[sel].float().numpy(), N(wt[s]), N(pre.b[s]), stride=(st, st), padding=(pad, pad),
+                                             dilation=(dil, dil))).max() < 1e-4
+        assert_close_scaled(y[s], full, 1e-5, "conv %s sample %d, all %d images" % ((B, C, O, H, W, k, st, pad, dil), s, B))
+        worst = max(worst, float(np.abs(y[s] - full).max()))
+    assert np.isfinite(worst)
 
 
 def test_conv_dense_path_equals_panel_path_and_trains(env):
@@ -487,3 +500,107 @@ def test_single_row_samples_chain_through_padded_rows(env):
     b2 = ops._sample_affine_philox_raw(m2[2], m2[3], k2[1]).double()
     want = torch.einsum("smk,snk->smn", hc.double(), w2) + b2.unsqueeze(1)
     assert (y.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.pow(2).mean().sqrt().item())
+
+
+HEAD_SHAPES = [  # S, M, N (hidden), K, Nh, shared_x, relu
+    (8, 512, 1200, 1200, 10, False, True),         # the BASELINE pair: 128 x 160 tiles, 16 partials
+    (8, 512, 1200, 784, 10, True, True),
+    (4, 512, 1200, 1200, 10, False, True),         # 64 x 160 tiles
+    (1, 300, 1200, 264, 16, True, False),          # 32 x 160 tiles, ragged rows, 16 outputs, no ReLU
+    (2, 70, 200, 72, 3, False, True),              # ragged everything: N = 200 is 1.25 panels of 160, K tail
+    (3, 130, 72, 200, 10, True, True),             # N <= 80: 256 x 80 tile, one partial per panel
+    (2, 260, 264, 328, 7, False, False),           # 256 x 128 tile (N % 80 != 0, N >= 128)
+]
+
+
+@pytest.mark.parametrize("S,M,Nn,K,Nh,shared,relu", HEAD_SHAPES)
+def test_fused_head_equals_two_dense_launches_and_double(env, S, M, Nn, K, Nh, shared, relu):
+    """bnn_dense_forward_head (hidden layer + classifier head in one launch, the hidden activation never stored) against (a) the
+    two plain launches on the same drawn weights -- same bf16 products, fp32 sums in another order -- and (b) float64 on the
+    device's own bf16 operands with the hidden activation rounded to bf16; the MC reduction over the partial logits equals the
+    mean of the summed logits."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    ops, dev, lib = env["ops"], env["dev"], env["lib"]
+    hid = _post((Nn, K), 41, dev)
+    head = _post((Nh, Nn), 42, dev)
+    pre = ops.draw_layers([(*hid, DrawKey(3, 31, 0, S, 5, gen=1), DrawKey(3, 32, 0, S, 5, gen=1)),
+                           (*head, DrawKey(3, 33, 0, S, 5, gen=1), DrawKey(3, 34, 0, S, 5, gen=1))], S)
+    g = torch.Generator().manual_seed(S * 100 + M)
+    x = torch.randn((M, K) if shared else (S, M, K), generator=g).to(dev).bfloat16()
+    xs = 0 if shared else M * K
+    n0 = lib.bnn_launch_count()
+    hp = ops._dense_head_raw(x, xs, M, pre[0], K, relu, pre[1])
+    assert lib.bnn_launch_count() == n0 + 1
+    parts = lib.bnn_dense_head_parts(M, Nn, S)
+    assert hp.p.shape == (parts, S, M, Nh) and parts >= 1
+    got = hp.logits()
+    # (a) the two plain launches
+    h = ops._dense_raw(x, xs, M, pre[0], K, relu, torch.bfloat16, pad_rows=True)
+    ld = h.stride(-2) if M > 1 else Nn
+    y2 = ops._dense_raw(h, h.stride(0), M, pre[1], Nn, False, torch.float32, ldx=ld)
+    assert_close_scaled(N(got), N(y2), 1e-5, "fused head vs two launches")
+    # (b) float64 on the same bf16 operands
+    xd = x.double().cpu() if not shared else x.double().cpu().unsqueeze(0).expand(S, M, K)
+    w1 = pre[0].w[:, :, :K].double().cpu(); b1 = pre[0].b.double().cpu()
+    w2 = pre[1].w[:, :, :Nn].double().cpu(); b2 = pre[1].b.double().cpu()
+    hh = torch.einsum("smk,snk->smn", xd, w1) + b1.unsqueeze(1)
+    if relu:
+        hh = hh.clamp_min(0)
+    hh = hh.float().bfloat16().double()
+    want = torch.einsum("smk,snk->smn", hh, w2) + b2.unsqueeze(1)
+    # a hidden value within fp32 rounding of a bf16 boundary may round the other way: one bf16 ulp of one addend
+    tol = 1e-5 + 2.0 ** -8 * float((w2.abs().max() * hh.abs().max()) / max(1.0, float(want.pow(2).mean().sqrt())))
+    assert_close_scaled(N(got), want.numpy(), tol, "fused head vs float64")
+    # the step's tail: ONE launch reduces the partials over (part, sample)
+    n1 = lib.bnn_launch_count()
+    pm = ops.mc_mean(hp)
+    assert lib.bnn_launch_count() == n1 + 1 and pm.shape == (M, Nh)
+    assert_close_scaled(N(pm), N(got).astype(np.float64).mean(0), 1e-5, "mc_mean over partial logits")
+    assert torch.equal(pm, ops.mc_mean(hp))                                     # fixed order: bitwise reproducible
+
+
+def test_predictive_mean_fuses_the_head_and_matches_forward_stacked(env):
+    """BayesianNetworkModule.predictive_mean on a fuse_activations'ed MLP in the bf16 mode: 4 launches (draw, layer 1, layer 2 +
+    head, reduction) instead of 5, the same predictive mean as forward_stacked(...).mean(0) on the same seed, the head's keys
+    recorded as its own sample() would; outside predictive_mean (forward / forward_stacked) nothing changes."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalLinear, BayesianNetworkModule, fuse_activations
+    dev, lib = env["dev"], env["lib"]
+    torch.manual_seed(9)
+
+    class Net(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(96, 10, 4)
+            self.layers = torch.nn.Sequential(NormalLinear(96, 160), torch.nn.ReLU(), NormalLinear(160, 240), torch.nn.ReLU(), NormalLinear(240, 10))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    net = Net().to(dev)
+    net.mc_batched = True
+    fuse_activations(net, bf16_activations=True)
+    assert net.layers[2].__dict__.get("_fuse_head") is net.layers[4] and net.layers[0].__dict__.get("_fuse_head") is None
+    x = torch.randn(70, 96, device=dev)
+    bnn.set_compute("bf16")
+    try:
+        with torch.no_grad():
+            bnn.manual_seed(21)
+            n0 = lib.bnn_launch_count()
+            ys = net.forward_stacked(x, 4)
+            assert lib.bnn_launch_count() == n0 + 4 and ys.shape == (4, 70, 10)          # draw + three layers
+            keys_plain = net.layers[4].weight.draw_key
+            bnn.manual_seed(21)
+            n0 = lib.bnn_launch_count()
+            pm = net.predictive_mean(x, 4)
+            assert lib.bnn_launch_count() == n0 + 4                                       # draw, layer 1, layer 2 + head, reduction
+            kf = net.layers[4].weight.draw_key
+            assert (kf.seed, kf.stream, kf.sample0, kf.nsamples, kf.epoch_host, kf.gen) == \
+                   (keys_plain.seed, keys_plain.stream, keys_plain.sample0, keys_plain.nsamples, keys_plain.epoch_host, keys_plain.gen)
+        assert_close_scaled(N(pm), N(ys).astype(np.float64).mean(0), 1e-5, "predictive_mean vs forward_stacked().mean(0)")
+        # with gradients wanted the pair is not fused (the backward needs the hidden activation)
+        bnn.manual_seed(21)
+        pm_g = net.predictive_mean(x, 4)
+        assert pm_g.requires_grad or net.layers[4].weight.mean.grad is None
+        assert_close_scaled(N(pm_g), N(pm), 1e-5, "predictive_mean with grad enabled")
+    finally:
+        bnn.set_compute("f32")

@@ -136,10 +136,10 @@ def test_tolerance_bookkeeping_k784_goldens(env):
     the reference's own fp32 sgemm is further from exact arithmetic than 1e-5 absolute there.  With numbers: against the
     float64 evaluation of the same network on the same fp32 weights,
         (i) max |HIP fp32 mode - f64|, (ii) max |reference fp32 - f64| (stored by make_golden.py).
-    Measured on MI355X: (i) = 1.4e-4, (ii) = 6.6e-5 at output rms 36 -- both a few 1e-6 OF THE OUTPUT SCALE, (i) about twice
-    (ii): three layers of bf16x3 contractions (six of nine partial products, 3.2e-7 of the scale each) against MKL's sgemm.
-    The 1e-5 absolute bar would reject both; the scaled bar (3.6e-4 here) holds both with margin.  Asserted: (i) inside the
-    scaled tolerance with 2x margin, and (i) <= 4 (ii)."""
+    Measured on MI355X (round 3): (i) = 5.4e-5 / 6.3e-5, (ii) = 6.6e-5 / 7.2e-5 at output rms 36 -- both ~2e-6 OF THE OUTPUT
+    SCALE: three layers of bf16x3 contractions (six of nine partial products, the five small ones summed apart from the
+    large one) against MKL's sgemm.  The 1e-5 absolute bar would reject both; the scaled bar (3.6e-4 here) holds both with
+    margin.  Asserted: (i) inside the scaled tolerance with 2x margin, (i) <= (ii), (i) <= 1e-4."""
     g = load_golden("mlp_784_1200_1200_10")
     g64 = load_golden("mlp_784_1200_1200_10_f64")
     dev = env["dev"]
@@ -171,7 +171,11 @@ def test_tolerance_bookkeeping_k784_goldens(env):
               % (s, ours, ref, ref_vs_golden, float(np.sqrt((g64["y%d_f64" % s] ** 2).mean()))))
         rms = float(np.sqrt((g64["y%d_f64" % s] ** 2).mean()))
         assert ours <= 0.5 * 1e-5 * rms, (ours, rms)    # half the scaled tolerance the goldens are judged by
-        assert ours <= 4.0 * ref, (ours, ref)           # the same order as the reference's own distance from exact arithmetic
+        # round 3: NO FARTHER from exact arithmetic than the reference's own fp32 sgemm (round 2 asserted 4 x: the small
+        # partial products of the bf16x3 contraction were accumulated into the large sum block by block; they now have an
+        # accumulator of their own / a sweep over K of their own -- 1.36e-4 / 1.66e-4 became 5.4e-5 / 6.3e-5 against 6.6e-5 / 7.2e-5)
+        assert ours <= ref, (ours, ref)
+        assert ours <= 1.0e-4, ours
         assert abs(ref - ref_vs_golden) <= 1e-6         # the stored reference error is the golden's own distance
     import json, os
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
