@@ -306,6 +306,7 @@ struct DenseParams {
     int32_t Nh;
 };
 
+constexpr int kDenseLoaderPrio = 1 << 21;   // internal flag (BNN_DENSE_LOADER_PRIO=1): loader waves at priority 2 (experiment)
 constexpr int kDenseNoXcdMap = 1 << 20;     // internal flag (BNN_DENSE_XCD=0): plain sample-major block order, for A/B runs
 
 // one LDS-DMA piece, scalar-base form: 64 lanes x 16 B from (base + voff) land at lds + 16 * lane
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     if (wave >= NWV) {
         // =============================== loader ===============================
         const int lw = wave - NWV;
+        if (p.flags & kDenseLoaderPrio) __builtin_amdgcn_s_setprio(2);
         const uint32_t ring = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
         // Lane l writes position l & 7 of row l >> 3 of its piece and therefore fetches chunk (l & 7) ^ (l >> 3) of
         // that row (the image's XOR swizzle, applied on the source address).
@@ -1149,6 +1151,8 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
     }
     static const bool no_xcd = [] { const char *e = getenv("BNN_DENSE_XCD"); return e && e[0] == '0'; }();
     if (no_xcd) p.flags |= kDenseNoXcdMap;
+    static const bool lprio = [] { const char *e = getenv("BNN_DENSE_LOADER_PRIO"); return e && e[0] == '1'; }();
+    if (lprio) p.flags |= kDenseLoaderPrio;
     // tile: the BASELINE-shaped layers (N % 80 == 0: 1200 = 7.5 x 160) take 128 x 160 with a 4-stage ring -- 36 KiB per
     // 64-k step instead of 256 x 80's 42 for the same MFMAs, 4 x 8 x 8 = 256 workgroups; wide layers 256 x 128.
     // BNN_DENSE_TILE = 0 (256 x 80), 1 (128 x 160), 2 (256 x 128), 3 (64 x 160), 4 (32 x 160) forces one for A/B runs.

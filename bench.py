@@ -22,7 +22,8 @@ Prints ONE JSON line (rank 0).  Extra keys: `checked` / `checked_f32` (one more 
 with the CPU oracle on the replay's own draw keys -- a checker, never timed; N > 1: the all-reduced buffer against global
 sample ids, every rank replays, rank 0 compares), `device_error_word`, `roofline` (dominant
 kernel, measured live with events on the launch stream), `roofline_conv_lenet` / `roofline_conv_cifar`
-/ `roofline_wide_f32` (configs[2], [3], [4] layer launches), `cpu_baseline` (torch-CPU port of the
+/ `roofline_wide_f32` (configs[2], [3], [4] layer launches), `roofline_lenet_net` / `roofline_wide_stack` (configs[2] and [4] as
+the whole networks they name), `cpu_baseline` (torch-CPU port of the
 reference, N = 1 only), `f32` (same step in the fp32 parity mode), `train` (N = 1: the reference's
 training-loop body, examples/MNIST/train.py:53-65, on the same model).
 """
@@ -685,6 +686,95 @@ def wide_roofline(dev, iters=5):
             "algorithmic_bytes_per_launch": 8.0 * (N * K + N) + 4.0 * M * (K + N)}
 
 
+def lenet_net_roofline(mode, dev):
+    """configs[2] as the NETWORK the reference ships (examples/MNIST/model.py:20-33, the same architecture the FashionMNIST
+    config names with Normal* layers): three stock Conv2d (+ BatchNorm, ELU) -- run ONCE per forward, they see no weight
+    noise -- then NormalConv2d(64, 64, 3, s2, p1), ELU, NormalLinear(576, 10), Softmax over 8 MC samples in one batched pass
+    (mc_batched), eval mode, batch 1024 (examples/FashionMNIST/train.py:16).  One captured graph per forward.  Random-init
+    weights of that architecture, synthetic 28 x 28 inputs.  FLOPs: the Bayesian layers x 8 samples + the prefix once."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import BayesianNetworkModule, NormalConv2d, NormalLinear
+    from torch.nn import Conv2d, BatchNorm2d, ELU, Softmax, Flatten, Sequential
+    B = 1024
+
+    class BCNN(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(1, 10, SAMPLES)
+            self.layers = Sequential(Conv2d(1, 32, 5, padding=2, stride=2), BatchNorm2d(32), ELU(), Conv2d(32, 32, 3, padding=1, stride=1), ELU(),
+                                     Conv2d(32, 64, 3, padding=0, stride=2), ELU(), NormalConv2d(64, 64, 3, padding=1, stride=2), ELU(), Flatten(),
+                                     NormalLinear(576, 10), Softmax(dim=-1))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    torch.manual_seed(13)
+    net = BCNN().to(dev).eval()
+    net.mc_batched = True
+    x = torch.randn(B, 1, 28, 28, device=dev)
+    prev = bnn.get_compute()
+    bnn.set_compute(mode)
+    try:
+        with torch.no_grad():
+            us = _graph_time(lambda: net.forward_stacked(x, SAMPLES), dev, reps=4, iters=10)
+            us_prefix = _graph_time(lambda: net.layers[:7](x), dev, reps=4, iters=10)
+    finally:
+        bnn.set_compute(prev)
+    f_bayes = SAMPLES * (2.0 * B * 9 * 64 * 576 + 2.0 * B * 576 * 10)
+    f_prefix = 2.0 * B * (196 * 32 * 25 + 196 * 32 * 288 + 36 * 64 * 288)
+    ach = (f_bayes + f_prefix) / us / 1e6
+    return {"kernel": "examples/MNIST/model.py BCNN, batch 1024, 8 MC samples per forward (mc_batched, eval): stock conv prefix once + "
+                      "NormalConv2d 64->64 k3 s2 p1 + ELU + NormalLinear 576->10 + softmax on all samples",
+            "mc_samples_per_s": round(SAMPLES / us * 1e6, 1), "avg_forward_us": round(us, 1), "prefix_us": round(us_prefix, 1),
+            "bayesian_part_us": round(us - us_prefix, 1),
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[mode], "unit": "TFLOP/s", "frac": round(ach / PEAK[mode], 5),
+            "algorithmic_flop_per_forward": f_bayes + f_prefix, "bayesian_flop_per_forward": f_bayes,
+            "bayesian_part_tflops": round(f_bayes / max(us - us_prefix, 1e-3) / 1e6, 2), "traffic": None,
+            "note": "the stock prefix (MIOpen convolutions on 1-32-64 channels) is torch's; the Bayesian layers are this engine's"}
+
+
+def wide_stack_roofline(dev):
+    """configs[4] as the STACK it names: 8 x NormalLinear(4096, 4096) with ReLU between, batch 4096, fp32 parity mode, ONE MC
+    sample per forward -- 1.0995 TFLOP per MC sample.  mc_batched pass with nn.fuse_activations: ONE draw launch for all
+    eight layers (three bf16 planes each), the input split once, hidden activations handed on as three planes."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import BayesianNetworkModule, NormalLinear, fuse_activations
+    D, B, L = 4096, 4096, 8
+
+    class Stack(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(D, D, 1)
+            mods = []
+            for i in range(L):
+                mods.append(NormalLinear(D, D))
+                if i < L - 1:
+                    mods.append(torch.nn.ReLU())
+            self.layers = torch.nn.Sequential(*mods)
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    torch.manual_seed(14)
+    net = Stack().to(dev)
+    net.mc_batched = True
+    fuse_activations(net, bf16_activations=True)
+    x = torch.randn(B, D, device=dev)
+    prev = bnn.get_compute()
+    bnn.set_compute("f32")
+    try:
+        with torch.no_grad():
+            ms = _time_launches(lambda: net._forward_batched_stacked(x, 1, 0), dev, 4, warm=2)
+    finally:
+        bnn.set_compute(prev)
+    flops = 2.0 * B * L * D * D
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "8 x NormalLinear(4096, 4096) + ReLU, batch 4096, fp32 parity mode, 1 MC sample per forward: draw launches (three bf16 "
+                      "planes) + one split of the input + 8 x k_dense_bf16<4,8,4,1,3> on three-plane operands",
+            "mc_samples_per_s": round(1e3 / ms, 2), "avg_forward_ms": round(ms, 3),
+            "bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK_X3, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_X3, 4),
+            "peak_note": "fp32-equivalent FLOP/s of the whole forward; peak = bf16 dense MFMA peak / 6; native fp32 MFMA peak %.1f" % PEAK["f32"],
+            "algorithmic_flop_per_forward": flops, "algorithmic_bytes_per_forward": 8.0 * L * (D * D + D) + 4.0 * B * D * 2, "traffic": None}
+
+
 def sampler_roofline(dev, iters=20):
     """K1 alone on a working set beyond the Infinity Cache (64 Mi scalars = 768 MiB of traffic):
     HBM-bound, 8 B read + 4 B written per scalar."""
@@ -974,6 +1064,8 @@ def main(argv=None):
             line["roofline_conv_lenet"] = conv_roofline("lenet", args.dtype, dev)
             line["roofline_conv_cifar"] = conv_roofline("cifar", args.dtype, dev)
             line["roofline_wide_f32"] = wide_roofline(dev)
+            line["roofline_lenet_net"] = lenet_net_roofline(args.dtype, dev)
+            line["roofline_wide_stack"] = wide_stack_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(post, x_cpu)
         if failures:
