@@ -254,7 +254,14 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
             uint16_t *rowp = reinterpret_cast<uint16_t *>(t_out + ((int64_t)row * t_ld) * 2 + s * sbytes);
             for (int j = 0; j < nval; ++j) {
                 const int col = c0 + j, c = col / t_taps, tp = col - c * t_taps;
-                rowp[tp * Cn + c] = f2bf(w[j]);
+                if (t_x3) {
+                    uint32_t h, m, l;
+                    split_bf16x3(w[j], 0.f, h, m, l);
+                    rowp[tp * Cn + c] = (uint16_t)h;
+                    *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(rowp + tp * Cn + c) + pbytes) = (uint16_t)m;
+                    *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(rowp + tp * Cn + c) + 2 * pbytes) = (uint16_t)l;
+                } else
+                    rowp[tp * Cn + c] = f2bf(w[j]);
             }
         } else {
             // a bias, or the ragged end of a row whose padding starts inside this group: values, then zeros
@@ -794,6 +801,10 @@ struct ConvParams {
     //   y[b][o] = conv(x[b], mean)[o] + R[b][o] * conv(x[b] * S[b], stddev)[o]           (conv.py:207-221)
     const float *sgn_in;        // S: B x C of +-1
     const float *sgn_out;       // R: B x O of +-1
+    // fp32 parity mode (X3 instantiation, bnn_conv2d_dense_forward_x3): W is THREE bf16 planes (plane stride in elements), the
+    // resident images are split into three planes in LDS, and every 64-k block is walked on the six plane pairs of
+    // k_dense_bf16's parity mode -- the five small pairs for every block first, then (h, h) over all of K
+    int64_t w_plane_stride;
 };
 
 constexpr int kConvLds = 78 * 1024;      // two workgroups per CU (O = 64)
@@ -802,9 +813,10 @@ constexpr int kConvLdsBig = 136 * 1024;  // one workgroup per CU with a 6-stage 
 // FLIP: the Flipout estimator in ONE launch -- the tile's columns are [O means | O stddevs] (TN = 2 O / 16), both
 // contractions share the A fragment: the second one takes it with the sign bits of S flipped in (a 16-B mask per
 // (image, 8-channel chunk), built in LDS next to the images), and R multiplies its accumulator in the epilogue.
-template <int TN, int ST, int LDSB, bool FLIP = false>
+template <int TN, int ST, int LDSB, bool FLIP = false, bool X3 = false>
 __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(const ConvParams p)
 {
+    static_assert(!(FLIP && X3), "the Flipout launch is a bf16-mode path");
     constexpr int NWV = 4, TM = 2, WM = 32, BN = 16 * TN;
     constexpr int B_TOTAL = BN / 8, NBP = B_TOTAL / NWV;        // B pieces per loader per stage (TN = 4: 2, TN = 8: 4)
     constexpr int B_STAGE = BN * 128;
@@ -814,9 +826,10 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
     const int P = p.OH * p.OW, HW = p.H * p.Wd;
     const int CPX = p.C >> 3;                                   // 16-B chunks per pixel
     const int mask_region = FLIP ? p.IMG * CPX * 16 : 0;        // sign masks [image][chunk]
-    const int img_region = p.IMG * p.img_bytes;
-    char *masks = lds + img_region;
-    char *b_ring = lds + img_region + mask_region;
+    const int img_region = p.IMG * p.img_bytes;        // one plane of this tile's images
+    constexpr int NPL = X3 ? 3 : 1;
+    char *masks = lds + NPL * img_region;
+    char *b_ring = lds + NPL * img_region + mask_region;
     constexpr int NOUT = FLIP ? BN / 2 : BN;                    // output channels of the tile
 
     int s, t;
@@ -831,7 +844,8 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool swz16 = (p.C >> 3) >= 16;
     auto swz = [&](int pl) { return swz16 ? (pl & 15) : ((pl >> 1) & 7); };
-    const int nk = p.KH * p.KW * (p.C >> 6);
+    const int nkb = p.KH * p.KW * (p.C >> 6);          // 64-k blocks: (tap, 64 channels)
+    const int nk = nkb * (X3 ? 6 : 1);
 
     // ---- loaders put the first ST - 1 weight stages in flight before anything else
     const int lw = wave - NWV;
@@ -840,9 +854,16 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
     const char *w_base = reinterpret_cast<const char *>(p.W + (int64_t)s * p.w_sample_stride);
     auto issue = [&](int kt) {
         const int stage = kt % ST;
+        int kb = kt;
+        const char *wb = w_base;
+        if constexpr (X3) {
+            int pr = 5;
+            if (kt < 5 * nkb) { kb = kt / 5; pr = kt - 5 * kb; } else kb = kt - 5 * nkb;
+            wb += ((0x010120 >> (4 * pr)) & 3) * (p.w_plane_stride * 2);      // the W plane of pair pr: h l m h m h
+        }
 #pragma unroll
         for (int j = 0; j < NBP; ++j)
-            dma_piece(w_base, b_off[j] + (uint32_t)(kt * 128), b_lds + (uint32_t)(stage * B_STAGE + (lw + NWV * j) * 1024));
+            dma_piece(wb, b_off[j] + (uint32_t)(kb * 128), b_lds + (uint32_t)(stage * B_STAGE + (lw + NWV * j) * 1024));
     };
     if (wave >= NWV) {
         b_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(b_ring));
@@ -912,7 +933,17 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
                     if (il + u < imgs) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (dst[j] >= 0) *reinterpret_cast<uint32_t *>(lds + (il + u) * p.img_bytes + dst[j]) = pack_bf16x2(va[u][j], vb[u][j]);
+                            if (dst[j] >= 0) {
+                                char *q = lds + (il + u) * p.img_bytes + dst[j];
+                                if constexpr (X3) {
+                                    uint32_t h, m, l;
+                                    split_bf16x3(va[u][j], vb[u][j], h, m, l);
+                                    *reinterpret_cast<uint32_t *>(q) = h;
+                                    *reinterpret_cast<uint32_t *>(q + img_region) = m;
+                                    *reinterpret_cast<uint32_t *>(q + 2 * img_region) = l;
+                                } else
+                                    *reinterpret_cast<uint32_t *>(q) = pack_bf16x2(va[u][j], vb[u][j]);
+                            }
                     }
             }
         }
@@ -959,49 +990,89 @@ __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(co
         const int fb0 = fi * 128 + (((0 + fq) ^ (fi & 7)) << 4), fb1 = fi * 128 + (((4 + fq) ^ (fi & 7)) << 4);
         const int CB = p.C >> 6;
         const int pixb = p.C * 2;
-        for (int kt = 0; kt < nk_run; ++kt) {
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int tap = kt / CB, cb = kt - tap * CB;
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const char *Bs = b_ring + (kt % ST) * B_STAGE;
-            int aoff[TM];
-            bool ok[TM];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int ih = ih0[a] + kh * p.dh, iw = iw0[a] + kw * p.dw;
-                ok[a] = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd;
-                const int pl = ok[a] ? ih * p.Wd + iw : 0;
-                aoff[a] = ib[a] + pl * pixb + (((cb * 8 + fq) ^ swz(pl)) << 4);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint4 af[TM], bfr[TN];
-#pragma unroll
-                for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const uint4 *>(Bs + (h ? fb1 : fb0) + b * 2048);
+        // Fragment registers are double-buffered over the two 32-k halves of a step and barrier t + 1 sits in the MIDDLE of
+        // step t, as in k_dense_bf16: [reads (t, h1) || MFMAs (t, h0)] [reads done -> barrier t + 1] [reads (t + 1, h0) || MFMAs
+        // (t, h1)] -- every group of fragment reads is in flight under the previous group's MFMAs.  (Round 2 read the 2 + TN
+        // fragments of a half and then multiplied: at O = 128 a step was 0.61 us for 0.24 us of MFMA issue.)
+        uint4 fa[2][TM], fbr[2][TN], fmk[2][FLIP ? TM : 1];
+        // (tap row, tap column, 64-channel block) of the step whose h0 half is read next: advanced by rd(.., h0), no divisions
+        // in the loop; the step's fragment addresses are kept for its h1 half
+        int s_kh = 0, s_kw = 0, s_cb = 0, s_stage = 0, cur_cb = 0;
+        int s_pr = 0, s_kt = 0;                             // X3: plane pair of the step, step index
+        int aoff[TM];
+        bool okk[TM];
+        const char *Bs = b_ring;
+        auto rd = [&](auto buf_c, auto h_c) {
+            constexpr int buf = decltype(buf_c)::value, h = decltype(h_c)::value;
+            if constexpr (h == 0) {
+                Bs = b_ring + s_stage * B_STAGE;
+                cur_cb = s_cb;
+                int aplane = 0;
+                if constexpr (X3) aplane = ((0x001102 >> (4 * s_pr)) & 3) * img_region;        // the A plane of pair pr: l h m m h h
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
-                    // chunk (cb 8 + 4 h + fq) ^ swz: h flips bit 2 of the chunk index, i.e. 64 bytes of the address
-                    const uint4 v = *reinterpret_cast<const uint4 *>(lds + (h ? (aoff[a] ^ 64) : aoff[a]));
-                    af[a] = ok[a] ? v : make_uint4(0u, 0u, 0u, 0u);
+                    const int ih = ih0[a] + s_kh * p.dh, iw = iw0[a] + s_kw * p.dw;
+                    okk[a] = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd;
+                    const int pl = okk[a] ? ih * p.Wd + iw : 0;
+                    aoff[a] = aplane + ib[a] + pl * pixb + (((s_cb * 8 + fq) ^ swz(pl)) << 4);
                 }
-                uint4 afs[TM];
-                if constexpr (FLIP) {
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        const uint4 m = *reinterpret_cast<const uint4 *>(masks + mb[a] + (cb * 8 + 4 * h + fq) * 16);
-                        afs[a] = make_uint4(af[a].x ^ m.x, af[a].y ^ m.y, af[a].z ^ m.z, af[a].w ^ m.w);
-                    }
+                s_stage = s_stage + 1 == ST ? 0 : s_stage + 1;
+                bool next_block = true;
+                if constexpr (X3) {
+                    // sweep 1 (steps < 5 nkb): pairs 0..4 of a block, then the next block; sweep 2: pair 5 of every block
+                    ++s_kt;
+                    if (s_kt < 5 * nkb) { next_block = s_pr == 4; s_pr = next_block ? 0 : s_pr + 1; }
+                    else if (s_kt == 5 * nkb) { s_pr = 5; next_block = false; s_cb = s_kw = s_kh = 0; }
                 }
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) {
-                        const uint4 av = (FLIP && b >= TN / 2) ? afs[a] : af[a];
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
-                                                                            __builtin_bit_cast(bf16x8, bfr[b]), acc[a][b], 0, 0, 0);
-                    }
+                if (next_block) { if (++s_cb == CB) { s_cb = 0; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } } }
             }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fbr[buf][b] = *reinterpret_cast<const uint4 *>(Bs + (h ? fb1 : fb0) + b * 2048);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                // chunk (cb 8 + 4 h + fq) ^ swz: h flips bit 2 of the chunk index, i.e. 64 bytes of the address
+                const uint4 v = *reinterpret_cast<const uint4 *>(lds + (h ? (aoff[a] ^ 64) : aoff[a]));
+                fa[buf][a] = okk[a] ? v : make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (FLIP) fmk[buf][a] = *reinterpret_cast<const uint4 *>(masks + mb[a] + (cur_cb * 8 + 4 * h + fq) * 16);
+            }
+        };
+        auto mm = [&](auto buf_c) {
+            constexpr int buf = decltype(buf_c)::value;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                uint4 afs = fa[buf][a];
+                if constexpr (FLIP) {
+                    const uint4 m = fmk[buf][a];
+                    afs = make_uint4(afs.x ^ m.x, afs.y ^ m.y, afs.z ^ m.z, afs.w ^ m.w);
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const uint4 av = (FLIP && b >= TN / 2) ? afs : fa[buf][a];
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                        __builtin_bit_cast(bf16x8, fbr[buf][b]), acc[a][b], 0, 0, 0);
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        if (nk_run > 0) {
+            __builtin_amdgcn_s_barrier();                                   // barrier 0: stage 0 has landed
+            asm volatile("" ::: "memory");
+            rd(I0{}, I0{});
+            for (int kt = 0; kt + 1 < nk_run; ++kt) {
+                rd(I1{}, I1{});
+                mm(I0{});
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of stage kt have returned
+                __builtin_amdgcn_s_barrier();                               // barrier kt + 1
+                asm volatile("" ::: "memory");
+                rd(I0{}, I0{});
+                mm(I1{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rd(I1{}, I1{});
+            mm(I0{});
+            mm(I1{});
         }
     }
 
@@ -1230,7 +1301,7 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         d.kind = t.kind;
         if (t.kind < 0 || t.kind > 2) { set_error("%s: tensor %d: kind must be 0 (draw), 1 (mean) or 2 (stddev)", who, i); return BNN_E_RANGE; }
         if (t.out_dtype == BNN_BF16X3 && t.kind != 0) { set_error("%s: tensor %d: three-plane output is for draws (kind 0)", who, i); return BNN_E_UNSUPPORTED; }
-        if (t.taps > 1 && (t.cols % t.taps != 0 || t.out_dtype != BNN_BF16)) { set_error("%s: tensor %d: taps must divide cols (bf16 output)", who, i); return BNN_E_SHAPE; }
+        if (t.taps > 1 && (t.cols % t.taps != 0 || t.out_dtype == BNN_F32)) { set_error("%s: tensor %d: taps must divide cols (bf16 or three-plane output)", who, i); return BNN_E_SHAPE; }
         d.first_item = (int32_t)items;
         d.rng = make_rng(&t.rng);
         const int64_t nit = t.rows * ((t.ld + 7) / 8);
@@ -1328,9 +1399,10 @@ int bnn_split_bf16x3(const float *x, int64_t rows, int64_t cols, int64_t ldx, vo
 static int conv_dense_launch(const float *x, int64_t x_sample_stride, const void *w, int64_t w_sample_stride, int64_t ldw,
                              const float *b, int64_t b_sample_stride, const float *sgn_in, const float *sgn_out,
                              float *y, int64_t y_sample_stride, const bnn_conv2d_shape_t *sh, int nsamples, int flags,
-                             void *stream, const char *who)
+                             void *stream, const char *who, int64_t w_plane_stride = 0)
 {
     const bool flip = sgn_in != nullptr;
+    const bool x3 = w_plane_stride != 0;
     if (!x || !w || !y || !sh || (flip && !sgn_out)) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
     if (sh->B < 1 || sh->C < 1 || sh->H < 1 || sh->W < 1 || sh->O < 1 || sh->KH < 1 || sh->KW < 1 || sh->stride_h < 1 ||
         sh->stride_w < 1 || sh->pad_h < 0 || sh->pad_w < 0 || sh->dil_h < 1 || sh->dil_w < 1 || nsamples < 1) { set_error("%s: bad shape", who); return BNN_E_SHAPE; }
@@ -1348,11 +1420,13 @@ static int conv_dense_launch(const float *x, int64_t x_sample_stride, const void
     ConvParams p{};
     const int64_t img_bytes = (int64_t)sh->H * sh->W * sh->C * 2 + (flip ? (sh->C / 8) * 16 : 0);   // + the image's sign masks
     const int P = OH * OW;
-    const int st = bn == 64 ? 4 : (flip ? 4 : 6);       // ring stages (8 KB / 16 KB each)
-    const int64_t lds_block = bn == 64 ? kConvLds : kConvLdsBig;
+    if (x3 && (flip || w_plane_stride % 8 != 0 || w_plane_stride < (int64_t)sh->O * ldw)) { set_error("%s: bad plane stride", who); return BNN_E_SHAPE; }
+    // ring stages (8 KB / 16 KB each); three-plane operands: the big block for both widths (three image planes), 4 / 3 stages
+    const int st = bn == 64 ? 4 : (flip ? 4 : x3 ? 3 : 6);
+    const int64_t lds_block = (bn == 64 && !x3) ? kConvLds : kConvLdsBig;
     const int64_t ring = (int64_t)st * bn * 128;
     int img = 128 / P;                                  // rows per workgroup <= 128
-    while (img > 0 && (img * img_bytes + ring > lds_block || (int64_t)img * sh->O * P * 4 > lds_block)) --img;
+    while (img > 0 && (img * img_bytes * (x3 ? 3 : 1) + ring > lds_block || (int64_t)img * sh->O * P * 4 > lds_block)) --img;
     if (img > sh->B) img = sh->B;
     if (img < 1 || (int64_t)bn * ldw * 2 >= ((int64_t)1 << 32)) { set_error("%s: one image (%lld B bf16) + the weight ring do not fit the LDS block, or more than 128 output pixels per image", who, (long long)img_bytes); return BNN_E_UNSUPPORTED; }
     p.X = x; p.x_sample_stride = x_sample_stride;
@@ -1360,6 +1434,7 @@ static int conv_dense_launch(const float *x, int64_t x_sample_stride, const void
     p.bias = b; p.bias_sample_stride = b_sample_stride;
     p.Y = y; p.y_sample_stride = y_sample_stride;
     p.sgn_in = sgn_in; p.sgn_out = sgn_out;
+    p.w_plane_stride = w_plane_stride;
     p.B = sh->B; p.C = sh->C; p.H = sh->H; p.Wd = sh->W; p.O = sh->O; p.KH = sh->KH; p.KW = sh->KW;
     p.sh = sh->stride_h; p.sw = sh->stride_w; p.ph = sh->pad_h; p.pw = sh->pad_w; p.dh = sh->dil_h; p.dw = sh->dil_w;
     static const int cdiag = [] { const char *e = getenv("BNN_CONV_DIAG"); return e ? atoi(e) : 0; }();
@@ -1370,7 +1445,10 @@ static int conv_dense_launch(const float *x, int64_t x_sample_stride, const void
     if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
     const dim3 g((unsigned)grid), blk(512);
     hipStream_t stq = (hipStream_t)stream;
-    if (flip) {
+    if (x3) {
+        if (bn == 64) hipLaunchKernelGGL((k_conv_bf16<4, 4, kConvLdsBig, false, true>), g, blk, 0, stq, p);
+        else hipLaunchKernelGGL((k_conv_bf16<8, 3, kConvLdsBig, false, true>), g, blk, 0, stq, p);
+    } else if (flip) {
         if (bn == 64) hipLaunchKernelGGL((k_conv_bf16<4, 4, kConvLds, true>), g, blk, 0, stq, p);
         else hipLaunchKernelGGL((k_conv_bf16<8, 4, kConvLdsBig, true>), g, blk, 0, stq, p);
     } else {
@@ -1390,6 +1468,17 @@ int bnn_conv2d_dense_forward(const float *x, int64_t x_sample_stride,
 {
     return conv_dense_launch(x, x_sample_stride, w, w_sample_stride, ldw, b, b_sample_stride, nullptr, nullptr, y, y_sample_stride,
                              sh, nsamples, flags, stream, "bnn_conv2d_dense_forward");
+}
+
+int bnn_conv2d_dense_forward_x3(const float *x, int64_t x_sample_stride,
+                                const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
+                                const float *b, int64_t b_sample_stride,
+                                float *y, int64_t y_sample_stride,
+                                const bnn_conv2d_shape_t *sh, int nsamples, int flags, void *stream)
+{
+    if (w_plane_stride <= 0) { set_error("bnn_conv2d_dense_forward_x3: plane stride"); return BNN_E_SHAPE; }
+    return conv_dense_launch(x, x_sample_stride, w, w_sample_stride, ldw, b, b_sample_stride, nullptr, nullptr, y, y_sample_stride,
+                             sh, nsamples, flags, stream, "bnn_conv2d_dense_forward_x3", w_plane_stride);
 }
 
 int bnn_conv2d_flipout_forward(const float *x, const void *w, int64_t ldw, const float *sign_in, const float *sign_out,

@@ -823,12 +823,28 @@ def conv_dense_eligible(sh, OH, OW):
     return img_bytes + st * sh.O * 128 <= block and sh.O * P * 4 <= block
 
 
+_CONV_LDS_X3 = {64: (136 * 1024, 4), 128: (136 * 1024, 3)}   # fp32 parity mode: three image planes, the big block for both widths
+CONV_X3_F32 = os.environ.get("BNN_CONV_X3", "1") != "0"      # fp32 parity mode of eligible inference convolutions without the im2col panel
+
+
+def conv_dense_x3_eligible(sh, OH, OW):
+    """Shapes bnn_conv2d_dense_forward_x3 takes: as conv_dense_eligible with three bf16 planes of an image resident."""
+    if sh.groups != 1 or not (sh.C == 64 or sh.C % 128 == 0) or sh.O not in (64, 128):
+        return False
+    P = OH * OW
+    if P > 128:
+        return False
+    block, st = _CONV_LDS_X3[sh.O]
+    return 3 * sh.H * sh.W * sh.C * 2 + st * sh.O * 128 <= block and sh.O * P * 4 <= block
+
+
 class _SampledConv2d(torch.autograd.Function):
     """y[s] = conv2d(x[s], w_s, b_s, ...) as an implicit GEMM with in-kernel draws
     (NormalConv2d.forward, conv.py:112-119)."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, conv_args, compute):
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, conv_args, compute, track=True):
+        # track: grad mode at the call (inside forward it is always off, and needs_input_grad only mirrors requires_grad)
         require_cuda_f32(x, "x")
         require_cuda_f32(mu_w, "weight.mean")
         require_cuda_f32(rho_w, "weight.scale")
@@ -855,6 +871,20 @@ class _SampledConv2d(torch.autograd.Function):
                                                         ptr(pre.b), sh.O if pre.b is not None else 0, ptr(y),
                                                         sh.B * sh.O * OH * OW, ctypes.byref(sh), S, 0, stream_ptr(x.device)),
                   "bnn_conv2d_dense_forward")
+            return y
+        needs_grad = track and any(ctx.needs_input_grad[:5])
+        if (compute == _lib.COMPUTE_F32 and CONV_X3_F32 and not needs_grad and conv_dense_x3_eligible(sh, OH, OW) and
+                mu_w.data_ptr() % 16 == 0):
+            # fp32 parity mode, inference: the same implicit GEMM on three bf16 planes per operand -- weights drawn once as
+            # planes (tap-major), images split into planes as they become resident in LDS, six plane pairs per 64-k block; no
+            # im2col panel (the backward still takes the panel kernels, so training-time forwards stay on them)
+            K = mu_w[0].numel()
+            pre = draw_layers([(mu_w.reshape(sh.O, K), rho_w.reshape(sh.O, K), mu_b, rho_b, key_w, key_b, sh.KH * sh.KW)], S, x3=True)[0]
+            kp = pre.w.shape[3]
+            check(_lib.load().bnn_conv2d_dense_forward_x3(ptr(x), 0 if shared_x else per, ptr(pre.w), S * sh.O * kp, sh.O * kp, kp,
+                                                           ptr(pre.b), sh.O if pre.b is not None else 0, ptr(y),
+                                                           sh.B * sh.O * OH * OW, ctypes.byref(sh), S, 0, stream_ptr(x.device)),
+                  "bnn_conv2d_dense_forward_x3")
             return y
         rw = _rng_struct(key_w, x.device)
         rb = _rng_struct(key_b, x.device) if mu_b is not None else None
@@ -897,7 +927,7 @@ class _SampledConv2d(torch.autograd.Function):
         if need_b:
             gb = gy.sum((1, 3, 4))
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
-        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None
 
     @staticmethod
     def _backward_panel(ctx, gy, sh, OH, OW, need_x, need_w, need_b):
@@ -953,7 +983,7 @@ class _SampledConv2d(torch.autograd.Function):
         if need_b:
             gb = _colsum_raw(rows)                                          # (S, O)
             g_mu_b, g_rho_b = _sample_affine_bwd_raw(gb, rho_b, rho_b.numel(), S, key=ctx.key_b)
-        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None
+        return gx, g_mu_w, g_rho_w, g_mu_b, g_rho_b, None, None, None, None, None, None
 
 
 def conv2d_flipout_eligible(x, mean, stride, padding, dilation, groups):
@@ -1021,7 +1051,7 @@ def conv2d_sampled(x, mu_w, rho_w, mu_b, rho_b, key_w, key_b, shared_x, stride, 
                                 None if rho_b is None else rho_b.contiguous(),
                                 key_w, key_b, shared_x,
                                 (tuple(stride), tuple(padding), tuple(dilation), int(groups)),
-                                _compute_code(compute))
+                                _compute_code(compute), torch.is_grad_enabled())
 
 
 class _PlainConv2d(torch.autograd.Function):

@@ -238,7 +238,7 @@ typedef struct bnn_draw_tensor {
     int64_t ld;                 /* >= cols (% 8 == 0 when rows > 1); columns cols .. ld - 1 are written as ZEROS */
     int64_t out_sample_stride;  /* elements */
     int out_dtype;              /* BNN_F32, BNN_BF16, or BNN_BF16X3: three planes, plane p of draw s at
-                                 * out + (p * nsamples + s) * out_sample_stride (kind 0, taps <= 1) */
+                                 * out + (p * nsamples + s) * out_sample_stride (kind 0) */
     int kind;                   /* 0: draw mu + sigma(rho) eps (rng used); 1: mu itself; 2: sigma(rho) itself (no eps: Flipout's
                                  * two operands, nsamples = 1) */
     int taps;                   /* 0 / 1: rows are written as they are.  KH * KW of a conv weight (O, C, KH, KW) viewed as
@@ -433,6 +433,17 @@ int bnn_conv2d_dense_forward(const float *x, int64_t x_sample_stride,
                              float *y, int64_t y_sample_stride,
                              const bnn_conv2d_shape_t *shape, int nsamples, int flags, void *stream);
 
+/* The same convolution in the fp32 PARITY mode (1e-5 against the reference): w is a BNN_BF16X3 operand (three bf16 planes,
+ * w_plane_stride elements apart: bnn_draw_multi with out_dtype BNN_BF16X3 and taps = KH * KW), the images are split into
+ * three bf16 planes as they become resident in LDS, and every 64-k block is contracted on the six largest plane pairs of
+ * (xh + xm + xl)(wh + wm + wl) with fp32 accumulation -- the five small pairs of every block first, then (h, h) over all of K,
+ * as bnn_dense_forward_x3 does.  No im2col panel, no workspace.  Same shapes as bnn_conv2d_dense_forward.
+ * replaces  F.conv2d(x, *self.sampled, ...)  pytorch_bayesian/nn/conv.py:116 */
+int bnn_conv2d_dense_forward_x3(const float *x, int64_t x_sample_stride,
+                                const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
+                                const float *b, int64_t b_sample_stride,
+                                float *y, int64_t y_sample_stride,
+                                const bnn_conv2d_shape_t *sh, int nsamples, int flags, void *stream);
 /* Flipout conv2d in ONE launch: y[b] = conv(x[b], mean) + R[b] * conv(x[b] * S[b], stddev) with per-example
  * sign tensors S (B x C) and R (B x O) of +-1 (conv.py:154-161).  w = [O rows of the mean | O rows of the stddev], bf16
  * tap-major (bnn_draw_multi with kind = 1 / 2 and taps = KH * KW), ldw >= roundup(C KH KW, 64).  Both contractions share

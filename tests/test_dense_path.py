@@ -604,3 +604,47 @@ def test_predictive_mean_fuses_the_head_and_matches_forward_stacked(env):
         assert_close_scaled(N(pm_g), N(pm), 1e-5, "predictive_mean with grad enabled")
     finally:
         bnn.set_compute("f32")
+
+
+@pytest.mark.parametrize("B,C,O,H,W,k,st,pad,dil,shared", CONV_CASES)
+def test_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, H, W, k, st, pad, dil, shared):
+    """NormalConv2d in the fp32 PARITY mode at inference (bnn_conv2d_dense_forward_x3: weights drawn as three bf16 planes,
+    images split into planes in LDS, six plane pairs per 64-k block, no im2col panel): 1e-5 of the output scale against
+    torch's conv2d in float64 on the K1 draw of the recorded keys -- EVERY image -- and pinned to the scalar oracle on a slice;
+    two launches (draw + contraction); with gradients wanted the layer stays on the panel kernels and agrees."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalConv2d
+    from bayesianneuralnetworks_amd import _mc
+    ops, orc, dev, lib = env["ops"], env["orc"], env["dev"], env["lib"]
+    assert ops.CONV_X3_F32
+    S = 8 if B >= 256 else 3
+    torch.manual_seed(B + C + O + 1)
+    layer = NormalConv2d(C, O, k, stride=st, padding=pad, dilation=dil).to(dev)
+    x = torch.randn(B if shared else S * B, C, H, W, generator=torch.Generator().manual_seed(2))
+    xd = x.to(dev)
+    bnn.set_compute("f32")
+    bnn.manual_seed(78)
+    n0 = lib.bnn_launch_count()
+    with torch.no_grad(), _mc.McContext(S, B, 0):
+        y = layer(xd)
+    assert lib.bnn_launch_count() == n0 + 2, "draw (three planes) + one contraction, no im2col"
+    OH, OW = y.shape[-2:]
+    y = N(y).reshape(S, B, O, OH, OW)
+    kw, kb = layer.weight.draw_key, layer.bias.draw_key
+    assert kw.gen == 0                                                           # the fp32 mode draws from the default stream
+    w = ops._sample_affine_philox_raw(layer.weight.mean.detach(), layer.weight.scale.detach(), kw).double().cpu()    # (S, O, C, k, k)
+    b = ops._sample_affine_philox_raw(layer.bias.mean.detach(), layer.bias.scale.detach(), kb).double().cpu()
+    x64 = x.double()
+    for s in range(S):
+        xs = x64 if shared else x64[s * B:(s + 1) * B]
+        full = torch.nn.functional.conv2d(xs, w[s], b[s], stride=st, padding=pad, dilation=dil).numpy()
+        assert_close_scaled(y[s], full, 1e-5, "fp32-mode conv %s sample %d" % ((B, C, O, H, W, k, st, pad, dil), s))
+    sel = [0, B - 1]
+    want = orc.conv2d((x if shared else x[:B])[sel].numpy(), w[0].float().numpy(), b[0].float().numpy(), stride=(st, st), padding=(pad, pad), dilation=(dil, dil))
+    assert_close_scaled(y[0][sel], want, 1e-5, "fp32-mode conv vs scalar oracle")
+    # training-time forward (gradients wanted): the panel kernels, same keys -> same values to 1e-5
+    with _mc.McContext(S, B, 0):
+        n1 = lib.bnn_launch_count()
+        yg = layer(xd, sample=False)
+    assert yg.requires_grad
+    assert_close_scaled(N(yg).reshape(S, B, O, OH, OW), y, 2e-5, "panel path vs implicit GEMM")
