@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     constexpr bool YBF = YM != 0;                       // YM: 0 fp32, 1 bf16, 2 three bf16 planes (h, m, l) of the fp32 result, 3 fused head (no output)
     constexpr int ESZ = YBF ? 2 : 4;
     constexpr int EPI_BYTES = ST * STAGE / NWV;
-    constexpr int EPI_A = (EPI_BYTES / (16 * WN * ESZ)) < TM ? (EPI_BYTES / (16 * WN * ESZ)) : TM;
+    constexpr int EPI_A = (EPI_BYTES / (16 * (WN * ESZ + 16))) < TM ? (EPI_BYTES / (16 * (WN * ESZ + 16))) : TM;
     static_assert(EPI_A >= 1, "a quarter of the ring must hold at least 16 output rows (epilogue staging)");
     __shared__ __attribute__((aligned(16))) char lds[ST * STAGE];
 
@@ -468,6 +468,11 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
 
     // =============================== consumer ===============================
     static_assert(ST == 3 || ST == 4, "ring depth");
+    // DIAG 6 (BNN_DENSE_STAMPS=<device pointer>, a diagnostic build whose outputs stay correct): consumer wave 0 of every
+    // workgroup leaves s_memrealtime stamps (100 MHz) -- entry, first stage landed, loop done, stores issued, stores retired --
+    // in a buffer of its own (5 x uint64 per workgroup); no output value depends on them
+    uint64_t stamp[5] = {0, 0, 0, 0, 0};
+    if constexpr (DIAG == 6) stamp[0] = __builtin_amdgcn_s_memrealtime();
     const int fi = lane & 15, fq = lane >> 4;
     const int wm = wave / NWN, wn = wave % NWN;
     // LDS: [wm][stage][WM rows] for A, then [wn][stage][WN rows] for B -- every fragment of a wave within 64 KiB of its two
@@ -511,8 +516,12 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[buf][a]),
-                                                                    __builtin_bit_cast(bf16x8, fb[buf][b]), acc[a][b], 0, 0, 0);
+                // operands SWAPPED (w rows as the MFMA's A, x rows as its B): the accumulator block is the TRANSPOSE of the output
+                // block -- lane (i, q), register r holds output row i, column 4 q + r -- so a lane's four values are four
+                // CONSECUTIVE columns of one output row and leave as one 8-B (bf16) / 16-B (fp32) LDS write in the epilogue,
+                // instead of four 2-B writes to four rows (320 ds_write_b16 per wave: 2.0 us of a 12.6-us workgroup)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[buf][b]),
+                                                                    __builtin_bit_cast(bf16x8, fa[buf][a]), acc[a][b], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -548,8 +557,21 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
         interleave();
         __builtin_amdgcn_sched_barrier(0);
     };
+    // the bias of this wave's columns, requested BEFORE the loop (4 TN registers): loaded in the epilogue it was a full memory
+    // round trip in front of the first store (stamps: 2.0 us from the last MFMA to the stores' issue)
+    const float *bias = p.bias ? p.bias + (int64_t)s * p.bias_sample_stride : nullptr;
+    const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+    float bv[TN][4];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nw + b * 16 + fq * 4 + r;
+            bv[b][r] = (bias && n < p.N) ? bias[n] : 0.f;
+        }
     if constexpr (DIAG != 5) __builtin_amdgcn_s_barrier();         // barrier 0
     asm volatile("" ::: "memory");
+    if constexpr (DIAG == 6) stamp[1] = __builtin_amdgcn_s_memrealtime();
     rd(I0{}, 0u, I0{});
     uint32_t stage = 0;
     for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -565,34 +587,45 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // final barrier: every wave's last fragment read is behind it
     asm volatile("" ::: "memory");
+    if constexpr (DIAG == 6) stamp[2] = __builtin_amdgcn_s_memrealtime();
+    auto leave_stamps = [&]() {
+        if constexpr (DIAG == 6) {
+            stamp[3] = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp[4] = __builtin_amdgcn_s_memrealtime();
+            if (wave == 0 && lane == 0 && p.P) {
+                uint64_t *q = reinterpret_cast<uint64_t *>(p.P) + (int64_t)blockIdx.x * 5;
+                for (int i = 0; i < 5; ++i) q[i] = stamp[i];
+            }
+        }
+    };
 
-    // ---- epilogue: bias, activation, store (accumulator lane (i, q), register r = row 4 q + r, column i of a 16 x 16 block)
-    const float *bias = p.bias ? p.bias + (int64_t)s * p.bias_sample_stride : nullptr;
+    // ---- epilogue: bias, activation, store (accumulator lane (i, q), register r = output row i, column 4 q + r of a 16 x 16 block)
     const int64_t ybase = (int64_t)s * p.y_sample_stride * ESZ;
-    const int mw = m0 + wm * WM, nw = n0 + wn * WN;
-    float bv[TN];
+    // the lane's four values of block (a, b) after bias and activation
+    auto vals = [&](int a, int b, float (&v)[4]) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = nw + b * 16 + fi;
-        bv[b] = (bias && n < p.N) ? bias[n] : 0.f;
-    }
+        for (int r = 0; r < 4; ++r) {
+            v[r] = acc[a][b][r] + bv[b][r];
+            if (RELU) v[r] = fmaxf(v[r], 0.f);
+        }
+    };
     if constexpr (YM == 3) {
-        // ---- fused head: stage the wave's tile as bf16 rows (pitch 16 TN * 2 + 16 B: the 16 rows of a fragment read then hit
-        // 16 different bank groups), read it back as A fragments, one MFMA per (16-row block, 32 columns) against the head's
-        // weights for those hidden units (fragments straight from memory: Nh rows x 16 TN columns, read once per wave)
+        // ---- fused head: stage the wave's tile as bf16 rows (pitch 16 TN * 2 + 16 B: the 16 rows of a fragment read -- and
+        // of a staging write -- hit 16 different bank groups), read it back as A fragments, one MFMA per (16-row block, 32
+        // columns) against the head's weights for those hidden units (fragments straight from memory: Nh rows x 16 TN
+        // columns, read once per wave)
         constexpr int pitch = WN * 2 + 16;
         static_assert(WM * pitch <= EPI_BYTES, "the wave's quarter of the ring holds its bf16 tile");
         char *T = lds + wave * EPI_BYTES;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[a][b][r] + bv[b];
-                    if (RELU) v = fmaxf(v, 0.f);
-                    *reinterpret_cast<uint16_t *>(T + (a * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * 2) = f2bf(v);
-                }
+            for (int b = 0; b < TN; ++b) {
+                float v[4];
+                vals(a, b, v);
+                *reinterpret_cast<uint2 *>(T + (a * 16 + fi) * pitch + (b * 16 + fq * 4) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const int Nh = p.Nh;
@@ -614,6 +647,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
             for (int a = 0; a < TM; ++a) {
                 uint4 af = make_uint4(0u, 0u, 0u, 0u);
                 if (kcol < WN) af = *reinterpret_cast<const uint4 *>(T + (a * 16 + fi) * pitch + kcol * 2);
+                // (plain operand order: lane (i, q) of the result holds rows 4 q + r of the batch, head output i)
                 hacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), hacc[a], 0, 0, 0);
             }
         }
@@ -644,8 +678,9 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
                       ((reinterpret_cast<uintptr_t>(p.Y) + ybase) & 15u) == 0 && (NP == 1 || (p.y_plane_stride * ESZ) % 16 == 0);
     if (wide) {
         char *T = lds + wave * EPI_BYTES;
-        constexpr int pitch = WN * ESZ;
-        constexpr int cpr = pitch / 16;
+        constexpr int row_bytes = WN * ESZ;
+        constexpr int pitch = row_bytes + 16;           // + 16 B: the 16 rows of a staging write land in 16 different bank groups
+        constexpr int cpr = row_bytes / 16;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
             char *Y8 = reinterpret_cast<char *>(p.Y) + ybase + ((int64_t)pl * p.y_plane_stride + (int64_t)mw * p.ldy + nw) * ESZ;
@@ -654,16 +689,16 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
-                    for (int a = a0; a < a0 + EPI_A && a < TM; ++a)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = acc[a][b][r] + bv[b];
-                            if (RELU) v = fmaxf(v, 0.f);
-                            char *q = T + ((a - a0) * 16 + fq * 4 + r) * pitch + (b * 16 + fi) * ESZ;
-                            if (YM == 2) *reinterpret_cast<uint16_t *>(q) = plane_of(v, pl);
-                            else if (YM == 1) *reinterpret_cast<uint16_t *>(q) = f2bf(v);
-                            else *reinterpret_cast<float *>(q) = v;
-                        }
+                    for (int a = a0; a < a0 + EPI_A && a < TM; ++a) {
+                        float v[4];
+                        vals(a, b, v);
+                        char *q = T + ((a - a0) * 16 + fi) * pitch + (b * 16 + fq * 4) * ESZ;
+                        if (YM == 2)
+                            *reinterpret_cast<uint2 *>(q) = make_uint2((uint32_t)plane_of(v[0], pl) | ((uint32_t)plane_of(v[1], pl) << 16),
+                                                                       (uint32_t)plane_of(v[2], pl) | ((uint32_t)plane_of(v[3], pl) << 16));
+                        else if (YM == 1) *reinterpret_cast<uint2 *>(q) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        else *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's ds_writes before its ds_reads
                 __builtin_amdgcn_wave_barrier();
                 const int nrows = (TM - a0 < EPI_A ? TM - a0 : EPI_A) * 16;
@@ -676,28 +711,30 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        leave_stamps();
         return;
     }
     float *Yf = reinterpret_cast<float *>(p.Y) + (int64_t)s * p.y_sample_stride;
     uint16_t *Yh = reinterpret_cast<uint16_t *>(p.Y) + (int64_t)s * p.y_sample_stride;
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = nw + b * 16 + fi;
-        if (n >= p.N) continue;
+    for (int a = 0; a < TM; ++a) {
+        const int m = mw + a * 16 + fi;
+        if (m >= p.M) continue;
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int b = 0; b < TN; ++b) {
+            float v[4];
+            vals(a, b, v);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = mw + a * 16 + fq * 4 + r;
-                if (m >= p.M) continue;
-                float v = acc[a][b][r] + bv[b];
-                if (RELU) v = fmaxf(v, 0.f);
+                const int n = nw + b * 16 + fq * 4 + r;
+                if (n >= p.N) continue;
                 if (YM == 2) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) Yh[(int64_t)pl * p.y_plane_stride + (int64_t)m * p.ldy + n] = plane_of(v, pl);
-                } else if (YM == 1) Yh[(int64_t)m * p.ldy + n] = f2bf(v);
-                else Yf[(int64_t)m * p.ldy + n] = v;
+                    for (int pl = 0; pl < 3; ++pl) Yh[(int64_t)pl * p.y_plane_stride + (int64_t)m * p.ldy + n] = plane_of(v[r], pl);
+                } else if (YM == 1) Yh[(int64_t)m * p.ldy + n] = f2bf(v[r]);
+                else Yf[(int64_t)m * p.ldy + n] = v[r];
             }
+        }
     }
 }
 
@@ -1240,6 +1277,10 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
     const int64_t grid = (int64_t)p.ntm * p.ntn * nsamples;
     if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
     static const int diag = [] { const char *e = getenv("BNN_DENSE_DIAG"); return e ? atoi(e) : 0; }();
+    if (diag == 6 && !head) {
+        static const uint64_t stamps = [] { const char *e = getenv("BNN_DENSE_STAMPS"); return e ? strtoull(e, nullptr, 0) : 0ull; }();
+        p.P = reinterpret_cast<float *>(stamps);
+    }
     const bool relu = (flags & BNN_FLAG_RELU) != 0;
     const dim3 g((unsigned)grid), blk(512);
 #define BNN_DENSE_LAUNCH(TM_, TN_, NWM_, NWN_, ST_, RELU_) \
@@ -1252,6 +1293,7 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
         else if (diag == 3) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 3>), g, blk, 0, st, p); \
         else if (diag == 4) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 4>), g, blk, 0, st, p); \
         else if (diag == 5) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 5>), g, blk, 0, st, p); \
+        else if (diag == 6) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 6>), g, blk, 0, st, p); \
         else hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_>), g, blk, 0, st, p); \
     } while (0)
 #define BNN_DENSE_PICK(TM_, TN_, NWM_, NWN_, ST_) \
