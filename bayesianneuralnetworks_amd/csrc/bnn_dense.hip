@@ -59,6 +59,14 @@ struct DrawTensorDev {
     int32_t perm_taps;          // > 1: a conv weight (O, C, KH, KW) written tap-major: column c * taps + t -> t * (cols / taps) + c
     int32_t first_item;         // first work item (8-column group) of this tensor within the launch
     int32_t spread;             // 1: a small tensor -- one thread per (8-column group, MC sample) instead of per group
+    // flat (a large regular weight matrix): items first_item .. are the VALID 8-column groups in flat element order (item i =
+    // elements 8 i .. 8 i + 7: a workgroup = 2048 consecutive scalars = one workgroup of the KL's first pass), items pad_first ..
+    // the groups of the zero padding (rows x (ld - cols) / 8 of them, written as zeros by workgroups of their own)
+    int32_t flat, pad_first;
+    // kl_on: this tensor's KL partial sums are computed by its own draw items (the eight (mu, rho) are in registers): partial
+    // kl_first + workgroup index within the tensor; prior as in KlTensorDev
+    int32_t kl_on, kl_first;
+    float kl_prior_mu, kl_prior_sigma;
     RngDev rng;
 };
 struct DrawLaunch {
@@ -109,6 +117,84 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
     const RngDev rng = L.t[ti].rng;
     const int S = L.nsamples;
     int local = item0 + (int)threadIdx.x - L.t[ti].first_item;
+    if (L.t[ti].flat) {
+        // ================= a large regular weight matrix: flat items, KL partial sums from the items themselves =================
+        const int esz2 = 2;
+        const int64_t sbytes2 = t_stride * esz2, pbytes2 = sbytes2 * S;
+        const int padg = (t_ld - t_cols) >> 3;                          // padding groups per row
+        if (item0 >= L.t[ti].pad_first) {
+            // the zero padding beyond column `cols` (the dense kernel's K tail multiplies it with clamped, finite activations)
+            const int pi = item0 + (int)threadIdx.x - L.t[ti].pad_first;
+            const int prow = pi / (padg > 0 ? padg : 1);
+            if (padg == 0 || prow >= t_rows) return;
+            char *d0 = t_out + ((int64_t)prow * t_ld + t_cols + ((pi - prow * padg) << 3)) * esz2;
+            for (int s = (int)blockIdx.y; s < S; s += (int)gridDim.y)
+                for (int pl = 0; pl < (t_x3 ? 3 : 1); ++pl) *reinterpret_cast<uint4 *>(d0 + s * sbytes2 + pl * pbytes2) = make_uint4(0u, 0u, 0u, 0u);
+            return;
+        }
+        const int64_t e0 = (int64_t)local * 8;
+        const bool live = e0 < (int64_t)t_rows * t_cols;
+        float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0, r0 = m0, r1 = m0;
+        if (live) {
+            m0 = *reinterpret_cast<const float4 *>(t_mu + e0); m1 = *reinterpret_cast<const float4 *>(t_mu + e0 + 4);
+            r0 = *reinterpret_cast<const float4 *>(t_rho + e0); r1 = *reinterpret_cast<const float4 *>(t_rho + e0 + 4);
+        }
+        if (L.t[ti].kl_on && blockIdx.y == 0) {
+            // the first pass of this tensor's KL: kl_partial_block<8>'s thread sum (same eight scalars, same order) and reduction
+            const float inv_ps = __uint_as_float(uniform_vgpr(__float_as_uint(1.0f / L.t[ti].kl_prior_sigma)));
+            const float pmu = __uint_as_float(uniform_vgpr(__float_as_uint(L.t[ti].kl_prior_mu)));
+            float acc = 0.f;
+            if (live) {
+                acc += kl_elem(m0.x, r0.x, pmu, inv_ps); acc += kl_elem(m0.y, r0.y, pmu, inv_ps);
+                acc += kl_elem(m0.z, r0.z, pmu, inv_ps); acc += kl_elem(m0.w, r0.w, pmu, inv_ps);
+                acc += kl_elem(m1.x, r1.x, pmu, inv_ps); acc += kl_elem(m1.y, r1.y, pmu, inv_ps);
+                acc += kl_elem(m1.z, r1.z, pmu, inv_ps); acc += kl_elem(m1.w, r1.w, pmu, inv_ps);
+            }
+            kl_block_reduce(acc, L.t[ti].kl_first + ((item0 - L.t[ti].first_item) >> 8), L.kl.partials);
+        }
+        if (!live) return;
+        const int gpc = t_cols >> 3;                                    // valid groups per row (32-bit division)
+        const int row = local / gpc, c0 = (local - row * gpc) << 3;
+        const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        const float sg[8] = {sigma_draw(r0.x), sigma_draw(r0.y), sigma_draw(r0.z), sigma_draw(r0.w),
+                             sigma_draw(r1.x), sigma_draw(r1.y), sigma_draw(r1.z), sigma_draw(r1.w)};
+        const uint32_t edev = rng_epoch_dev(rng);
+        const PhiloxKeys keys = philox_keys(rng.key0, rng.key1);
+        const uint32_t blk = (uint32_t)(e0 >> 2);
+        const bool gen16 = rng.gen == BNN_GEN_PHILOX7_U16;      // (wave-uniform)
+        char *dst = t_out + ((int64_t)row * t_ld + c0) * esz2 + (int64_t)blockIdx.y * sbytes2;
+        const int64_t step = sbytes2 * (int64_t)gridDim.y;
+#pragma unroll U
+        for (int s = (int)blockIdx.y; s < S; s += (int)gridDim.y, dst += step) {
+            const uint32_t sample = rng.sample0 + (uint32_t)s;
+            float4 za, zb;
+            if (gen16) {
+                eps8_u16(rng, keys, edev, blk >> 1, sample, za, zb);    // the item IS one 8-eps block
+            } else {
+                za = eps4(rng, keys, edev, blk, sample);
+                zb = eps4(rng, keys, edev, blk + 1u, sample);
+            }
+            float w[8];
+            w[0] = fmaf(sg[0], za.x, m[0]); w[1] = fmaf(sg[1], za.y, m[1]);
+            w[2] = fmaf(sg[2], za.z, m[2]); w[3] = fmaf(sg[3], za.w, m[3]);
+            w[4] = fmaf(sg[4], zb.x, m[4]); w[5] = fmaf(sg[5], zb.y, m[5]);
+            w[6] = fmaf(sg[6], zb.z, m[6]); w[7] = fmaf(sg[7], zb.w, m[7]);
+            if (t_x3) {
+                uint4 h, mm, l;
+                split_bf16x3(w[0], w[1], h.x, mm.x, l.x); split_bf16x3(w[2], w[3], h.y, mm.y, l.y);
+                split_bf16x3(w[4], w[5], h.z, mm.z, l.z); split_bf16x3(w[6], w[7], h.w, mm.w, l.w);
+                *reinterpret_cast<uint4 *>(dst) = h;
+                *reinterpret_cast<uint4 *>(dst + pbytes2) = mm;
+                *reinterpret_cast<uint4 *>(dst + 2 * pbytes2) = l;
+            } else {
+                uint4 o;
+                o.x = pack_bf16x2(w[0], w[1]); o.y = pack_bf16x2(w[2], w[3]);
+                o.z = pack_bf16x2(w[4], w[5]); o.w = pack_bf16x2(w[6], w[7]);
+                *reinterpret_cast<uint4 *>(dst) = o;
+            }
+        }
+        return;
+    }
     const int gpr = (t_ld + 7) >> 3;                 // 8-column groups per output row
     // the samples this thread draws: s_lo, s_lo + s_step, ... < s_hi
     int s_lo = (int)blockIdx.y, s_hi = S, s_step = (int)gridDim.y;
@@ -420,7 +506,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
             constexpr int NBP = decltype(nbp_c)::value;
             constexpr int P = A_PIECES + NBP;           // VMEM ops of this wave per stage
             auto issue = [&](int kt) {
-                if constexpr (DIAG == 2 || DIAG == 5) return;
+                if constexpr (DIAG == 2 || DIAG == 5 || DIAG == 8 || DIAG == 9) return;
                 const int stage = kt % ST;
                 int kb = kt;
                 const char *ab = a_base, *wb = w_base;
@@ -456,7 +542,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
                 if (ST >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * P) : "memory");
                 else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if constexpr (DIAG != 5) __builtin_amdgcn_s_barrier();           // barrier kt: stage kt complete; stage (kt - 1) % ST is free
+                if constexpr (DIAG != 5 && DIAG != 9) __builtin_amdgcn_s_barrier();           // barrier kt: stage kt complete; stage (kt - 1) % ST is free
                 if (kt + ST - 1 < nk) issue(kt + ST - 1);
             }
             __builtin_amdgcn_s_barrier();               // final barrier: the consumers reuse the ring for the epilogue
@@ -472,7 +558,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     // workgroup leaves s_memrealtime stamps (100 MHz) -- entry, first stage landed, loop done, stores issued, stores retired --
     // in a buffer of its own (5 x uint64 per workgroup); no output value depends on them
     uint64_t stamp[5] = {0, 0, 0, 0, 0};
-    if constexpr (DIAG == 6) stamp[0] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DIAG >= 6) stamp[0] = __builtin_amdgcn_s_memrealtime();
     const int fi = lane & 15, fq = lane >> 4;
     const int wm = wave / NWN, wn = wave % NWN;
     // LDS: [wm][stage][WM rows] for A, then [wn][stage][WN rows] for B -- every fragment of a wave within 64 KiB of its two
@@ -501,7 +587,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     // 64 x 128 tile spilled)
     auto rd = [&](auto buf_c, uint32_t stage, auto h_c) {
         constexpr int buf = decltype(buf_c)::value, h = decltype(h_c)::value;
-        if constexpr (DIAG == 1) return;
+        if constexpr (DIAG == 1 || DIAG == 7) return;
         const char *As = a_rows + (stage * (uint32_t)(WM * 128) + (uint32_t)(h ? fbase1 : fbase0));
         const char *Bs = b_rows + (stage * (uint32_t)(WN * 128) + (uint32_t)(h ? fbase1 : fbase0));
 #pragma unroll
@@ -511,7 +597,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     };
     auto mm = [&](auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
-        if constexpr (DIAG == 1) return;
+        if constexpr (DIAG == 1 || DIAG == 7) return;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -529,7 +615,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     // TM + TN MFMAs: a read issued in an MFMA's shadow costs no issue time, and none is needed before the next phase
     // (block scheduling: the reads-then-MFMAs order cost ~250 cycles of a 900-cycle step with the MFMA pipe idle).
     auto interleave = [&]() {
-        if constexpr ((DIAG == 0 || DIAG >= 3) && INTERLEAVE) {
+        if constexpr ((DIAG == 0 || (DIAG >= 3 && DIAG != 7)) && INTERLEAVE) {
             constexpr int NI = (TM * TN) / MPR < TM + TN ? (TM * TN) / MPR : TM + TN;   // reads that get MFMAs in front of them
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -549,7 +635,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     };
     auto second_half = [&](uint32_t next) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's reads of stage t have returned
-        if constexpr (DIAG != 5) __builtin_amdgcn_s_barrier();      // barrier t + 1
+        if constexpr (DIAG != 5 && DIAG != 9) __builtin_amdgcn_s_barrier();      // barrier t + 1
         asm volatile("" ::: "memory");
         rd(I0{}, next, I0{});                           // (t + 1, h0) -> buffer 0
         if constexpr (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
@@ -569,9 +655,9 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
             const int n = nw + b * 16 + fq * 4 + r;
             bv[b][r] = (bias && n < p.N) ? bias[n] : 0.f;
         }
-    if constexpr (DIAG != 5) __builtin_amdgcn_s_barrier();         // barrier 0
+    if constexpr (DIAG != 5 && DIAG != 9) __builtin_amdgcn_s_barrier();         // barrier 0
     asm volatile("" ::: "memory");
-    if constexpr (DIAG == 6) stamp[1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DIAG >= 6) stamp[1] = __builtin_amdgcn_s_memrealtime();
     rd(I0{}, 0u, I0{});
     uint32_t stage = 0;
     for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -587,9 +673,9 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // final barrier: every wave's last fragment read is behind it
     asm volatile("" ::: "memory");
-    if constexpr (DIAG == 6) stamp[2] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DIAG >= 6) stamp[2] = __builtin_amdgcn_s_memrealtime();
     auto leave_stamps = [&]() {
-        if constexpr (DIAG == 6) {
+        if constexpr (DIAG >= 6) {
             stamp[3] = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp[4] = __builtin_amdgcn_s_memrealtime();
@@ -1277,7 +1363,7 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
     const int64_t grid = (int64_t)p.ntm * p.ntn * nsamples;
     if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
     static const int diag = [] { const char *e = getenv("BNN_DENSE_DIAG"); return e ? atoi(e) : 0; }();
-    if (diag == 6 && !head) {
+    if (diag >= 6 && diag <= 9 && !head) {
         static const uint64_t stamps = [] { const char *e = getenv("BNN_DENSE_STAMPS"); return e ? strtoull(e, nullptr, 0) : 0ull; }();
         p.P = reinterpret_cast<float *>(stamps);
     }
@@ -1294,6 +1380,9 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
         else if (diag == 4) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 4>), g, blk, 0, st, p); \
         else if (diag == 5) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 5>), g, blk, 0, st, p); \
         else if (diag == 6) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 6>), g, blk, 0, st, p); \
+        else if (diag == 7) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 7>), g, blk, 0, st, p); \
+        else if (diag == 8) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 8>), g, blk, 0, st, p); \
+        else if (diag == 9) hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_, 9>), g, blk, 0, st, p); \
         else hipLaunchKernelGGL((k_dense_bf16<TM_, TN_, NWM_, NWN_, ST_, 1, RELU_>), g, blk, 0, st, p); \
     } while (0)
 #define BNN_DENSE_PICK(TM_, TN_, NWM_, NWN_, ST_) \
@@ -1348,6 +1437,12 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         d.rng = make_rng(&t.rng);
         const int64_t nit = t.rows * ((t.ld + 7) / 8);
         d.spread = (nit < kDrawSpreadBelow && nsamples > 1 && nit * nsamples <= 0x7FFFFFFF) ? 1 : 0;
+        d.flat = (!d.spread && t.out_dtype != BNN_F32 && t.kind == 0 && t.taps <= 1 && t.cols % 8 == 0 && t.ld % 8 == 0 && al16(t.mu) && al16(t.rho)) ? 1 : 0;
+        if (d.flat) {
+            items += (t.rows * (t.cols / 8) + 255) / 256 * 256;             // the valid groups, flat ...
+            d.pad_first = (int32_t)items;
+            items += (t.rows * ((t.ld - t.cols) / 8) + 255) / 256 * 256;   // ... and the zero padding's
+        } else
         items += ((d.spread ? nit * nsamples : nit) + 255) / 256 * 256;     // a workgroup works on one tensor
         if (items > 0x7FFFFF00) { set_error("%s: too many elements for one call", who); return BNN_E_RANGE; }
     }
@@ -1359,6 +1454,28 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
             set_error("%s: the KL first pass cannot ride along (more than %d tensors, bad prior or no workspace): launch bnn_kl_forward_partial", who, kKlPiggyMax);
             return BNN_E_UNSUPPORTED;
         }
+        // a KL tensor that IS one of this launch's flat draw tensors (same mu / rho, all of it): its partial sums come from the
+        // draw items, which hold the posterior in registers -- no workgroups of its own, no second read of mu and rho (round 2:
+        // FETCH_SIZE of the launch 36.4 MB for 19.2 MB of posterior)
+        static const bool kl_items = [] { const char *e = getenv("BNN_DRAW_KL_ITEMS"); return !(e && e[0] == '0'); }();
+        int32_t launched = 0;
+        for (int j = 0; j < kl_ntensors; ++j) {
+            const int32_t nb = L.kl.pg_first[j + 1] - L.kl.pg_first[j];     // (pg_first still = first_block here)
+            bool in_items = false;
+            for (int i = 0; i < ntensors && kl_items && !in_items; ++i) {
+                DrawTensorDev &d = L.t[i];
+                if (d.flat && !d.kl_on && d.mu == kl_tensors[j].mu && d.rho == kl_tensors[j].rho &&
+                    kl_tensors[j].n == (int64_t)d.rows * d.cols) {
+                    d.kl_on = 1; d.kl_first = L.kl.t[j].first_block;
+                    d.kl_prior_mu = kl_tensors[j].prior_mu; d.kl_prior_sigma = kl_tensors[j].prior_sigma;
+                    in_items = true;
+                }
+            }
+            L.kl.pg_first[j] = launched;
+            if (!in_items) launched += nb;
+        }
+        L.kl.pg_first[kl_ntensors] = launched;
+        L.kl.nblocks = launched;
         grid += L.kl.nblocks;
     }
     // fewer than ~4 workgroups per CU: split the samples over gridDim.y too

@@ -146,7 +146,10 @@ static int kl_first_pass(const bnn_kl_tensor_t *tensors, int ntensors, double *p
     const bool huge = total >= ((int64_t)32 << 20);                // 32768-scalar workgroups (>= 1024 of them)
     // below 8 Mi scalars: 4096-scalar workgroups from 1 Mi on (the MLP's 2.4 M: step 0.1028 -> 0.1011 ms against 2048; 8192
     // was slower again), 2048 for small models so that they still spread over the chip
-    const int small_pt = total >= ((int64_t)1 << 20) ? 16 : 8;
+    // below 8 Mi scalars: 2048-scalar workgroups (a thread = eight consecutive scalars): the partial-sum layout the draw
+    // launch's items reproduce (bnn_draw_multi with kl_tensors).  (4096-scalar workgroups from 1 Mi scalars on were 1.7 %
+    // faster on the stand-alone KL of the 2.4-M MLP; in the step that first pass no longer reads the posteriors at all.)
+    const int small_pt = 8;
     const int64_t chunk = huge ? kKlThreads * 128 : big ? kKlThreads * 32 : kKlThreads * small_pt;
     for (int g0 = 0; g0 < ntensors; g0 += kKlMaxPerLaunch) {
         KlLaunch L{};
@@ -166,7 +169,6 @@ static int kl_first_pass(const bnn_kl_tensor_t *tensors, int ntensors, double *p
         if (launch) {
             if (huge) hipLaunchKernelGGL((k_kl_partial<32, 4>), dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
             else if (big) hipLaunchKernelGGL(k_kl_partial<32>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
-            else if (small_pt == 16) hipLaunchKernelGGL(k_kl_partial<16>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
             else hipLaunchKernelGGL(k_kl_partial<8>, dim3(blocks), dim3(kKlThreads), 0, st, L, partials);
             const int rc = check_launch(who);
             if (rc) return rc;
@@ -189,7 +191,7 @@ bool kl_plan_piggy(const bnn_kl_tensor_t *tensors, int ntensors, void *workspace
     int64_t total = 0;
     for (int t = 0; t < ntensors; ++t) total += tensors[t].n;
     if (total >= ((int64_t)8 << 20)) return false;                 // big models: their own launch fills the chip
-    const int pt = total >= ((int64_t)1 << 20) ? 16 : 8;           // == kl_first_pass's rule (the second pass rebuilds it)
+    const int pt = 8;                                              // == kl_first_pass's rule (the second pass rebuilds it)
     const int64_t chunk = (int64_t)kKlThreads * pt;
     int32_t blocks = 0;
     for (int i = 0; i < ntensors; ++i) {
@@ -197,8 +199,10 @@ bool kl_plan_piggy(const bnn_kl_tensor_t *tensors, int ntensors, void *workspace
         P.t[i].mu = s.mu; P.t[i].rho = s.rho; P.t[i].g_mu = nullptr; P.t[i].g_rho = nullptr;
         P.t[i].n = s.n; P.t[i].prior_mu = s.prior_mu; P.t[i].prior_sigma = s.prior_sigma;
         P.t[i].first_block = blocks; P.t[i].scale = 0.f;
+        P.pg_first[i] = blocks;                                    // (every tensor launched; a carrier that computes some itself re-packs)
         blocks += (int32_t)((s.n + chunk - 1) / chunk);
     }
+    P.pg_first[ntensors] = blocks;
     P.ntensors = ntensors;
     P.nblocks = blocks;
     P.pt = pt;

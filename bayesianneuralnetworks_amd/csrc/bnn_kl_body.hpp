@@ -69,6 +69,25 @@ __device__ __forceinline__ void kl_partial_block(const KlTensorDev &T, int block
     const float pmu = __uint_as_float(uniform_vgpr(__float_as_uint(T.prior_mu)));
     const bool vec = ((reinterpret_cast<uintptr_t>(T.mu) | reinterpret_cast<uintptr_t>(T.rho)) & 15u) == 0;
     double dacc = 0.0;
+    if constexpr (PT == 8 && REP == 1) {
+        // 2048-scalar workgroups: a thread takes EIGHT CONSECUTIVE scalars (two adjacent 16-B loads of mu and of rho) and adds
+        // their terms in index order -- the item of the draw launch (bnn_dense.hip, k_draw_multi), which holds the same eight
+        // (mu, rho) in registers and leaves the same partial sum without reading them again (kl_block_reduce below)
+        const int64_t e = base0 + (int64_t)threadIdx.x * 8;
+        float acc = 0.f;
+        if (vec && e + 8 <= T.n) {
+            const float4 m0 = *reinterpret_cast<const float4 *>(T.mu + e), m1 = *reinterpret_cast<const float4 *>(T.mu + e + 4);
+            const float4 r0 = *reinterpret_cast<const float4 *>(T.rho + e), r1 = *reinterpret_cast<const float4 *>(T.rho + e + 4);
+            acc += kl_elem(m0.x, r0.x, pmu, inv_ps); acc += kl_elem(m0.y, r0.y, pmu, inv_ps);
+            acc += kl_elem(m0.z, r0.z, pmu, inv_ps); acc += kl_elem(m0.w, r0.w, pmu, inv_ps);
+            acc += kl_elem(m1.x, r1.x, pmu, inv_ps); acc += kl_elem(m1.y, r1.y, pmu, inv_ps);
+            acc += kl_elem(m1.z, r1.z, pmu, inv_ps); acc += kl_elem(m1.w, r1.w, pmu, inv_ps);
+        } else {
+            for (int j = 0; j < 8; ++j)
+                if (e + j < T.n) acc += kl_elem(T.mu[e + j], T.rho[e + j], pmu, inv_ps);
+        }
+        dacc = (double)acc;
+    } else {
 #pragma unroll 1
     for (int rep = 0; rep < REP; ++rep) {
     const int64_t base = base0 + (int64_t)rep * (kKlThreads * PT);
@@ -114,7 +133,23 @@ __device__ __forceinline__ void kl_partial_block(const KlTensorDev &T, int block
     }
     dacc += (double)acc;
     }
+    }
     double d = wave_sum(dacc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kKlThreads / 64; ++w) s += red[w];
+        partials[partial_index] = s;
+    }
+}
+
+// The workgroup reduction of kl_partial_block on a thread sum computed elsewhere (the draw launch's items): same order, same
+// value.  All 256 threads of the workgroup call it.
+__device__ __forceinline__ void kl_block_reduce(float thread_sum, int partial_index, double *__restrict__ partials)
+{
+    __shared__ double red[kKlThreads / 64];
+    double d = wave_sum((double)thread_sum);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -129,9 +164,12 @@ constexpr int kKlPiggyMax = 8;
 struct KlPiggy {
     KlTensorDev t[kKlPiggyMax];
     int32_t ntensors;
-    int32_t nblocks;       // 0: nothing to carry
-    int32_t pt;            // 8 or 16
+    int32_t nblocks;       // workgroups to launch: 0 = nothing to carry
+    int32_t pt;            // 8 (2048-scalar workgroups)
     int32_t taken;         // host side: set by the launcher that carried it
+    // pg_first[i] .. pg_first[i + 1]: the launched workgroups of tensor i (none for a tensor whose partial sums the carrying
+    // launch computes itself: the draw launch's items); t[i].first_block stays the tensor's first PARTIAL index
+    int32_t pg_first[kKlPiggyMax + 1];
     double *partials;
 };
 
@@ -139,9 +177,9 @@ __device__ __forceinline__ void kl_piggy_block(const KlPiggy &P, int block)
 {
     int t = 0;
     for (int i = 1; i < P.ntensors; ++i)
-        if (block >= P.t[i].first_block) t = i;
-    if (P.pt == 16) kl_partial_block<16>(P.t[t], block, block, P.partials);
-    else kl_partial_block<8>(P.t[t], block, block, P.partials);
+        if (block >= P.pg_first[i]) t = i;
+    const int b = P.t[t].first_block + (block - P.pg_first[t]);
+    kl_partial_block<8>(P.t[t], b, b, P.partials);
 }
 
 // host: plan of a piggyback first pass (bnn_kl.hip); false = not eligible (caller launches bnn_kl_forward_partial)

@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 dev = torch.device("cuda:0")
 buf = torch.zeros(4096 * 5, dtype=torch.int64, device=dev)
-os.environ["BNN_DENSE_DIAG"] = "6"
+os.environ["BNN_DENSE_DIAG"] = os.environ.get("STAMP_DIAG", "6")
 os.environ["BNN_DENSE_STAMPS"] = hex(buf.data_ptr())
 from bayesianneuralnetworks_amd import _lib, ops
 from bayesianneuralnetworks_amd._rng import DrawKey
 import numpy as np
 import bench
-S, B = 8, 512
+S, B = 8, int(os.environ.get('STAMP_B', '512'))
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
 mw = torch.randn(1200, K, device=dev) * 0.03; rw = torch.full((1200, K), -2.0, device=dev)
 mb = torch.zeros(1200, device=dev); rb = torch.full((1200,), -2.0, device=dev)
@@ -24,10 +24,11 @@ for it in range(5):
     torch.cuda.synchronize()
     ops._dense_raw(h, B * ld, B, pre, K, True, torch.bfloat16, ldx=ld, pad_rows=True)
     torch.cuda.synchronize()
-st = buf.cpu().numpy().reshape(-1, 5)[:256].astype(np.float64) * 0.01    # us
+NWG = S * ((B + 127) // 128) * 8
+st = buf.cpu().numpy().reshape(-1, 5)[:NWG].astype(np.float64) * 0.01    # us
 t0 = st[:, 0].min()
 def q(v): return "p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % tuple(np.percentile(v, [10, 50, 90, 100]))
-print("K = %d (%d k-steps), 256 workgroups, times in us" % (K, (K + 63) // 64))
+print("DIAG %s, K = %d (%d k-steps), %d workgroups, times in us" % (os.environ["BNN_DENSE_DIAG"], K, (K + 63) // 64, NWG))
 print("workgroup start after the first      : " + q(st[:, 0] - t0))
 print("entry -> first stage landed          : " + q(st[:, 1] - st[:, 0]))
 print("main loop                            : " + q(st[:, 2] - st[:, 1]) + "   (per k-step p50 %.3f)" % (np.percentile(st[:, 2] - st[:, 1], 50) / ((K + 63) // 64)))
