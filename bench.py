@@ -56,15 +56,35 @@ PEAK_HBM_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
-def pmc_traffic(kernel_tag):
+def _pmc_entry(kernel_tag):
     try:
         with open(TRAFFIC_FILE) as f:
-            ent = json.load(f).get(kernel_tag)
+            return json.load(f).get(kernel_tag)
     except (OSError, ValueError):
-        return None, None
+        return None
+
+
+def pmc_traffic(kernel_tag):
+    ent = _pmc_entry(kernel_tag)
     if not ent:
         return None, None
     return ent.get("traffic_bytes"), {"file": ent.get("source"), "date": ent.get("date")}
+
+
+MAX_CLOCK_MHZ = 2400.0      # MI355X_MICROARCH.md: the clock the 2.5 PFLOP/s bf16 peak is quoted at
+
+
+def pmc_mfma_util(kernel_tag, launch_us):
+    """MFMA utilisation of a launch from the PMC pass recorded in profiles/pmc_traffic.json: the matrix pipe's busy cycles per
+    SIMD (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; = 16 cycles x the MFMAs a SIMD issued) over the launch's duration -- measured
+    live here -- in cycles of the MAXIMUM clock: a lower bound of the pipe's busy fraction (the chip holds ~1.85-2.0 GHz under
+    this loop, tools/dense_stamps.py: at that clock the same figure is ~1.25 x higher)."""
+    ent = _pmc_entry(kernel_tag)
+    if not ent or "mfma_busy_cycles_per_simd" not in ent or not launch_us:
+        return None
+    return {"mfma_util": round(ent["mfma_busy_cycles_per_simd"] / (launch_us * MAX_CLOCK_MHZ), 4),
+            "mfma_busy_cycles_per_simd": ent["mfma_busy_cycles_per_simd"], "mfma_insts_per_launch": ent.get("mfma_insts"),
+            "at_clock_mhz": MAX_CLOCK_MHZ, "source": ent.get("mfma_source"), "date": ent.get("date")}
 
 
 def posteriors(seed=0):
@@ -577,6 +597,7 @@ def kernel_roofline(net, x, mode, dev):
         out.update({"kernel": "k_dense_bf16<4,5,2,2,4> (128x160 tile, 4-stage ring): layer 2, 512x1200x1200 x8 samples on drawn weights (%s)" % tag,
                     "achieved": round(ach, 2), "frac": round(ach / PEAK[mode], 4), "avg_launch_us": round(us, 2),
                     "algorithmic_bytes_per_launch": SAMPLES * (BATCH * DIMS[1] * 2 + DIMS[2] * DIMS[1] * 2 + BATCH * DIMS[2] * 2),
+                    "mfma": pmc_mfma_util(tag, us),
                     "layer_end_to_end": {"draw_us": round(us_draw, 2), "total_us": round(us + us_draw, 2),
                                          "tflops": round(flops / (us + us_draw) / 1e6, 1),
                                          "frac": round(flops / (us + us_draw) / 1e6 / PEAK[mode], 4),

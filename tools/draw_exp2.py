@@ -8,7 +8,7 @@ import bench
 lib = _lib.load(); dev = torch.device("cuda:0")
 post = [[t.to(dev) for t in p] for p in bench.posteriors(0)]
 S = 8
-def K(i): return DrawKey(1, i, 0, S, 0)
+def K(i): return DrawKey(1, i, 0, S, 0, gen=1)
 full = [(mw, rw, mb, rb, K(2 * i + 1), K(2 * i + 2)) for i, (mw, rw, mb, rb) in enumerate(post)]
 nob = [(mw, rw, None, None, K(2 * i + 1), None) for i, (mw, rw, mb, rb) in enumerate(post)]
 print("all 6 tensors      : %.2f us" % bench._graph_time(lambda: ops.draw_layers(full, S), dev))

@@ -8,9 +8,9 @@ import bench
 dev = torch.device("cuda:0"); S, B = 8, 512
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 mw, rw, mb, rb = [t.to(dev) for t in bench.posteriors(0)[1]]
-pre = ops.draw_layers([(mw, rw, mb, rb, DrawKey(1, 1, 0, S, 0), DrawKey(1, 2, 0, S, 0))], S)[0]
+pre = ops.draw_layers([(mw, rw, mb, rb, DrawKey(1, 1, 0, S, 0, gen=1), DrawKey(1, 2, 0, S, 0, gen=1))], S)[0]
 h = torch.randn(S, B, 1200, device=dev).relu_().bfloat16()
 for _ in range(n):
     ops._dense_raw(h, B * 1200, B, pre, 1200, True, torch.bfloat16)
-    ops.draw_layers([(mw, rw, mb, rb, DrawKey(1, 1, 0, S, 0), DrawKey(1, 2, 0, S, 0))], S)
+    ops.draw_layers([(mw, rw, mb, rb, DrawKey(1, 1, 0, S, 0, gen=1), DrawKey(1, 2, 0, S, 0, gen=1))], S)
 torch.cuda.synchronize()
