@@ -655,6 +655,21 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
             const int n = nw + b * 16 + fq * 4 + r;
             bv[b][r] = (bias && n < p.N) ? bias[n] : 0.f;
         }
+    if (DIAG == 0 && (nw >= p.N || mw >= p.M)) {
+        // This wave's whole 16 TM x 16 TN tile lies in the padding of the grid (the BASELINE layers: N = 1200 is 7.5 column
+        // panels of 160 -- the second wave column of the last panel, 6.25 % of the launch's MFMAs, LDS reads and energy): it keeps
+        // the workgroup's barriers company and computes nothing.  (A fused head's partial slot of this wave is written as zeros:
+        // the reduction adds every slot.)
+        for (int kt = 0; kt < nk + 1; ++kt) __builtin_amdgcn_s_barrier();        // barrier 0, the nk - 1 mid-step ones, the final one
+        if constexpr (YM == 3) {
+            float *P = p.P + ((int64_t)(panel * NWN + wn) * p.S + s) * (int64_t)p.M * p.Nh;
+            for (int i = lane; i < WM * p.Nh; i += 64) {
+                const int m = mw + i / p.Nh;
+                if (m < p.M) P[(int64_t)m * p.Nh + (i % p.Nh)] = 0.f;
+            }
+        }
+        return;
+    }
     if constexpr (DIAG != 5 && DIAG != 9) __builtin_amdgcn_s_barrier();         // barrier 0
     asm volatile("" ::: "memory");
     if constexpr (DIAG >= 6) stamp[1] = __builtin_amdgcn_s_memrealtime();

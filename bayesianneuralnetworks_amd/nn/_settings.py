@@ -29,7 +29,7 @@ def fuse_kl_gradient(enable=True):
     ops.FUSE_KL_GRADIENT = bool(enable)
 
 
-def fuse_activations(module, bf16_activations=False):
+def fuse_activations(module, bf16_activations=False, fuse_head=False):
     """Opt-in graph rewrite inside every torch.nn.Sequential:
 
     * a `NormalLinear` directly followed by `torch.nn.ReLU` gets the ReLU folded into its kernel
@@ -42,9 +42,12 @@ def fuse_activations(module, bf16_activations=False):
       are identical to fp32 hidden activations; it halves the consumer's activation stream.  In the
       'f32' mode the same pairs (wide consumer, inference) pass the activation as the three bf16
       planes of its fp32 value (ops.X3Activation, exact to 2^-24), the operand format of the dense
-      kernel's parity mode.  A hidden layer whose consumer is the classifier head (<= 16 outputs) at the END of the
-      Sequential additionally learns that (`_fuse_head`): `BayesianNetworkModule.predictive_mean` then runs the pair as ONE
-      launch (bnn_dense_forward_head) and the head's logits exist only as partial sums that the MC reduction adds up.
+      kernel's parity mode.
+    * fuse_head=True (with bf16_activations): a hidden layer whose consumer is the classifier head (<= 16 outputs) at the END
+      of the Sequential additionally learns that (`_fuse_head`): `BayesianNetworkModule.predictive_mean` then runs the pair as
+      ONE launch (bnn_dense_forward_head) and the head's logits exist only as partial sums that the MC reduction adds up.
+      Opt-in because it is only right when `_forward` returns that Sequential's output AS IT IS (anything applied to the
+      logits afterwards -- a softmax -- would meet partial sums, not a tensor).
 
     Returns the number of fused pairs."""
     import torch
@@ -69,7 +72,7 @@ def fuse_activations(module, bf16_activations=False):
                         if j < len(mods) and type(mods[j]) is NormalLinear and mods[j].in_channels % 8 == 0:
                             # a narrow consumer that ENDS the Sequential: under predictive_mean (bf16 mode, inference) the pair
                             # runs as one launch (ops._dense_head_raw) -- the layer learns who its head is
-                            if mods[j].weight.mean.shape[0] <= 16 and j == len(mods) - 1:
+                            if fuse_head and mods[j].weight.mean.shape[0] <= 16 and j == len(mods) - 1:
                                 la.__dict__["_fuse_head"] = mods[j]      # (not a submodule registration)
                             la.out_dtype = torch.bfloat16
                             # ... and in the fp32 parity mode, when the consumer runs on the dense kernels too, as the three

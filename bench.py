@@ -139,7 +139,8 @@ def build_net(dev, post):
     from bayesianneuralnetworks_amd.nn import fuse_activations
     # ReLU folded into the GEMM epilogue; in bf16 mode hidden activations stay bf16 (the consumer
     # rounds them to bf16 anyway: identical results, half the activation stream)
-    fuse_activations(net, bf16_activations=True)
+    # ... and layer 2 may run fused with the classifier head behind it when the step asks for the predictive mean
+    fuse_activations(net, bf16_activations=True, fuse_head=True)
     return net
 
 

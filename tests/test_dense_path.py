@@ -579,6 +579,8 @@ def test_predictive_mean_fuses_the_head_and_matches_forward_stacked(env):
     net = Net().to(dev)
     net.mc_batched = True
     fuse_activations(net, bf16_activations=True)
+    assert net.layers[2].__dict__.get("_fuse_head") is None                         # opt-in: nothing fused without fuse_head=True
+    fuse_activations(net, bf16_activations=True, fuse_head=True)
     assert net.layers[2].__dict__.get("_fuse_head") is net.layers[4] and net.layers[0].__dict__.get("_fuse_head") is None
     x = torch.randn(70, 96, device=dev)
     bnn.set_compute("bf16")
