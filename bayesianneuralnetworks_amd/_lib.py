@@ -110,6 +110,8 @@ SIGNATURES = {
     "bnn_dense_head_parts": (_int, [_i64, _i64, _int]),
     "bnn_dense_forward_head": (_int, [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i64,
                                       _p, _i64, _i64, _i64, _int, _int, _p]),
+    "bnn_dense_forward_x3_head": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64,
+                                         _p, _i64, _i64, _p, _i64, _i64, _i64, _int, _int, _p]),
     "bnn_dense_forward_x3": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64,
                                     _i64, _i64, _i64, _int, _int, _p]),
     "bnn_split_bf16x3": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p]),

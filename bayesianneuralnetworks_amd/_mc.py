@@ -21,6 +21,8 @@ class McContext:
         # set by BayesianNetworkModule.predictive_mean: the caller reduces the outputs over the MC axis itself, so a hidden layer
         # may fuse the classifier head behind it and hand on partial logits (ops.HeadPartials) instead of a tensor
         self.lazy_head = False
+        # (x, planes): the network input and its three bf16 planes, split by the draw plan's launch (fp32 parity mode)
+        self.x_planes = None
 
     def __enter__(self):
         self.prev = getattr(_state, "ctx", None)

@@ -206,13 +206,19 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
         s_hi = s_lo < S ? s_lo + 1 : 0;
         s_step = 1;
     }
+    if (t_kind == 3) {
+        // kind 3: the tensor as it is, ONCE (not per sample): with a three-plane output this is bnn_split_bf16x3 of an
+        // activation -- the fp32 parity mode's input planes -- riding in the draw launch instead of a launch of its own
+        if (L.t[ti].spread ? s_lo != 0 : blockIdx.y != 0) return;
+        s_lo = 0; s_hi = 1; s_step = 1;
+    }
     const int row = local / gpr, c0 = (local - row * gpr) << 3;
     if (row >= t_rows) return;
     const int64_t orow = (int64_t)row * t_ld + c0;
     const int esz = t_bf16 ? 2 : 4;
     char *const dst0 = t_out + orow * esz;
     const int64_t sbytes = t_stride * esz;
-    const int64_t pbytes = sbytes * L.nsamples;     // (three-plane output)
+    const int64_t pbytes = sbytes * (t_kind == 3 ? 1 : L.nsamples);     // (three-plane output; kind 3: one copy, planes out_sample_stride apart)
     // ---- the regular case, where the time goes: a weight matrix drawn as bf16 (or as three bf16 planes) whose rows are whole,
     // 16-B aligned 8-column groups.  What decides the code path is wave-uniform (read off the tensor's descriptor), the sample
     // loop is straight-line code, and the groups in the zero padding run the same loop with mean = sigma = 0 (a few % of wasted
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
         // no draw: the posterior's mean or its stddev themselves (Flipout contracts on both, dense.py:70-83 / conv.py:207-221)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            m[j] = j < nval ? (t_kind == 1 ? t_mu[e0 + j] : sigma_accurate(t_rho[e0 + j])) : 0.f;
+            m[j] = j < nval ? (t_kind != 2 ? t_mu[e0 + j] : sigma_accurate(t_rho[e0 + j])) : 0.f;
             sg[j] = 0.f;
         }
     } else if (full) {
@@ -397,6 +403,7 @@ struct DenseParams {
     int64_t bias_h_sample_stride;
     float *P;
     int32_t Nh;
+    int64_t wh_plane_stride;    // x3: the head's weights are three bf16 planes too
 };
 
 constexpr int kDenseLoaderPrio = 1 << 21;   // internal flag (BNN_DENSE_LOADER_PRIO=1): loader waves at priority 2 (experiment)
@@ -712,6 +719,71 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
         }
     };
     if constexpr (YM == 3) {
+        constexpr bool X3_HEAD_FITS = 3 * WM * (WN * 2 + 16) <= EPI_BYTES;        // (the 128 / 64 / 32 x 160 tiles; the launcher refuses the others)
+        if constexpr (X3_HEAD_FITS) if (p.x3) {
+            // ---- fused head, fp32 parity mode: the fp32 tile is split into its three bf16 planes (exact to 2^-24), staged
+            // plane by plane, and contracted with the three planes of the head's weights on the six plane pairs of the main loop
+            // -- the five small ones into an accumulator of their own, (h, h) into another, added once
+            constexpr int pitch = WN * 2 + 16;
+            char *T = lds + wave * EPI_BYTES;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    float v[4];
+                    vals(a, b, v);
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split_bf16x3(v[0], v[1], h0, m0, l0);
+                    split_bf16x3(v[2], v[3], h1, m1, l1);
+                    char *q = T + (a * 16 + fi) * pitch + (b * 16 + fq * 4) * 2;
+                    *reinterpret_cast<uint2 *>(q) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(q + WM * pitch) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2 *>(q + 2 * WM * pitch) = make_uint2(l0, l1);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int Nh = p.Nh;
+            const int hrow = fi < Nh ? fi : Nh - 1;
+            const uint16_t *wh = p.Wh + (int64_t)s * p.wh_sample_stride + (int64_t)hrow * p.ldwh;
+            f32x4 hacc[TM], hsm[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) { hacc[a] = f32x4{0.f, 0.f, 0.f, 0.f}; hsm[a] = hacc[a]; }
+            constexpr int NC = (WN + 31) / 32;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int kcol = 32 * c + 8 * fq;
+                const int n = nw + kcol;
+                const bool okb = kcol < WN && fi < Nh && n + 8 <= (int)p.ldwh;
+                uint4 bf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bf[pl] = okb ? *reinterpret_cast<const uint4 *>(wh + pl * p.wh_plane_stride + n) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    uint4 af[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[pl] = kcol < WN ? *reinterpret_cast<const uint4 *>(T + pl * WM * pitch + (a * 16 + fi) * pitch + kcol * 2) : make_uint4(0u, 0u, 0u, 0u);
+                    auto mf = [&](f32x4 c4, int pa, int pw) {
+                        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[pa]), __builtin_bit_cast(bf16x8, bf[pw]), c4, 0, 0, 0);
+                    };
+                    hsm[a] = mf(mf(mf(mf(mf(hsm[a], 2, 0), 0, 2), 1, 1), 1, 0), 0, 1);      // (l,h) (h,l) (m,m) (m,h) (h,m)
+                    hacc[a] = mf(hacc[a], 0, 0);                                             // (h,h)
+                }
+            }
+            const int part = panel * NWN + wn;
+            float hb = 0.f;
+            if (part == 0 && p.bias_h && fi < Nh) hb = p.bias_h[(int64_t)s * p.bias_h_sample_stride + fi];
+            float *P = p.P + ((int64_t)part * p.S + s) * (int64_t)p.M * Nh;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mw + a * 16 + fq * 4 + r;
+                    if (m < p.M && fi < Nh) P[(int64_t)m * Nh + fi] = (hacc[a][r] + hsm[a][r]) + hb;
+                }
+            return;
+        }
         // ---- fused head: stage the wave's tile as bf16 rows (pitch 16 TN * 2 + 16 B: the 16 rows of a fragment read -- and
         // of a staging write -- hit 16 different bank groups), read it back as A fragments, one MFMA per (16-row block, 32
         // columns) against the head's weights for those hidden units (fragments straight from memory: Nh rows x 16 TN
@@ -1282,6 +1354,7 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float *__restrict__ 
 // the fused head's operands (dense_launch's `head`, NULL = the plain layer)
 struct HeadArgs {
     const void *wh;
+    int64_t wh_plane_stride;    // 0: plain bf16 operands
     int64_t wh_sample_stride, ldwh;
     const float *bh;
     int64_t bh_sample_stride;
@@ -1340,7 +1413,12 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
         p.a_plane_stride = x_plane_stride; p.w_plane_stride = w_plane_stride; p.y_plane_stride = y_plane_stride;
     }
     if (head) {
-        if (x3 || N <= 16 || (flags & BNN_FLAG_Y_BF16) == 0) { set_error("%s: the fused head follows a bf16 hidden layer wider than 16", who); return BNN_E_UNSUPPORTED; }
+        if (N <= 16 || (flags & BNN_FLAG_Y_BF16) == 0) { set_error("%s: the fused head follows a hidden layer wider than 16", who); return BNN_E_UNSUPPORTED; }
+        if (x3 && (head->wh_plane_stride % 8 != 0 || head->wh_plane_stride < head->nh * head->ldwh)) { set_error("%s: bad plane stride of the head's weights", who); return BNN_E_SHAPE; }
+        if (x3) {
+            const int t_ = dense_pick_tile(M, N, nsamples);
+            if (t_ == 0 || t_ == 2) { set_error("%s: the three-plane fused head runs on the 160-column tiles (N %% 80 == 0 or N < 128, N > 80)", who); return BNN_E_UNSUPPORTED; }
+        }
         if (!head->wh || head->nh < 1 || head->nh > 16) { set_error("%s: head of 1 .. 16 outputs", who); return BNN_E_SHAPE; }
         if (N % 8 != 0 || head->ldwh % 8 != 0 || head->ldwh < N || head->wh_sample_stride % 8 != 0 || !al16(head->wh) ||
             (reinterpret_cast<uintptr_t>(head->partials) & 3u)) {
@@ -1350,6 +1428,7 @@ static int dense_launch(const char *who, const void *x, int64_t x_plane_stride, 
         p.Wh = reinterpret_cast<const uint16_t *>(head->wh); p.wh_sample_stride = head->wh_sample_stride; p.ldwh = head->ldwh;
         p.bias_h = head->bh; p.bias_h_sample_stride = head->bh_sample_stride;
         p.P = head->partials; p.Nh = (int32_t)head->nh;
+        p.wh_plane_stride = head->wh_plane_stride;
     }
     hipStream_t st = (hipStream_t)stream;
     if (N <= 16 && K <= 4 * kHeadMaxSteps * 32) {
@@ -1445,8 +1524,8 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         d.rows = (int32_t)t.rows; d.cols = (int32_t)t.cols; d.ld = (int32_t)t.ld; d.bf16 = t.out_dtype == BNN_BF16 ? 1 : t.out_dtype == BNN_BF16X3 ? 2 : 0;
         d.perm_taps = t.taps > 1 ? t.taps : 1;
         d.kind = t.kind;
-        if (t.kind < 0 || t.kind > 2) { set_error("%s: tensor %d: kind must be 0 (draw), 1 (mean) or 2 (stddev)", who, i); return BNN_E_RANGE; }
-        if (t.out_dtype == BNN_BF16X3 && t.kind != 0) { set_error("%s: tensor %d: three-plane output is for draws (kind 0)", who, i); return BNN_E_UNSUPPORTED; }
+        if (t.kind < 0 || t.kind > 3) { set_error("%s: tensor %d: kind must be 0 (draw), 1 (mean), 2 (stddev) or 3 (as it is, once)", who, i); return BNN_E_RANGE; }
+        if (t.out_dtype == BNN_BF16X3 && t.kind != 0 && t.kind != 3) { set_error("%s: tensor %d: three-plane output is for draws (kind 0) and for kind 3", who, i); return BNN_E_UNSUPPORTED; }
         if (t.taps > 1 && (t.cols % t.taps != 0 || t.out_dtype == BNN_F32)) { set_error("%s: tensor %d: taps must divide cols (bf16 or three-plane output)", who, i); return BNN_E_SHAPE; }
         d.first_item = (int32_t)items;
         d.rng = make_rng(&t.rng);
@@ -1536,9 +1615,22 @@ int bnn_dense_forward_head(const void *x, int64_t x_sample_stride, int64_t ldx,
                            const float *b_head, int64_t bh_sample_stride, int64_t n_head,
                            float *partials, int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream)
 {
-    HeadArgs h{w_head, wh_sample_stride, ldwh, b_head, bh_sample_stride, partials, n_head};
+    HeadArgs h{w_head, 0, wh_sample_stride, ldwh, b_head, bh_sample_stride, partials, n_head};
     return dense_launch("bnn_dense_forward_head", x, 0, x_sample_stride, ldx, w, 0, w_sample_stride, ldw, b, b_sample_stride,
                         nullptr, 0, 0, N, M, N, K, nsamples, flags | BNN_FLAG_Y_BF16, false, stream, &h);
+}
+
+int bnn_dense_forward_x3_head(const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,
+                              const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
+                              const float *b, int64_t b_sample_stride,
+                              const void *w_head, int64_t wh_plane_stride, int64_t wh_sample_stride, int64_t ldwh,
+                              const float *b_head, int64_t bh_sample_stride, int64_t n_head,
+                              float *partials, int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream)
+{
+    if (wh_plane_stride <= 0) { set_error("bnn_dense_forward_x3_head: plane stride of the head's weights"); return BNN_E_SHAPE; }
+    HeadArgs h{w_head, wh_plane_stride, wh_sample_stride, ldwh, b_head, bh_sample_stride, partials, n_head};
+    return dense_launch("bnn_dense_forward_x3_head", x, x_plane_stride, x_sample_stride, ldx, w, w_plane_stride, w_sample_stride, ldw,
+                        b, b_sample_stride, nullptr, 0, 0, N, M, N, K, nsamples, flags | BNN_FLAG_Y_BF16, true, stream, &h);
 }
 
 int bnn_dense_forward_x3(const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,

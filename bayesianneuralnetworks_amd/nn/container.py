@@ -99,7 +99,7 @@ class BayesianNetworkModule(Module):
         B = x.shape[0]
         with _mc.McContext(samples, B, sample0) as ctx:
             ctx.lazy_head = _lazy_head
-            drawn = self._draw_plan(ctx)
+            drawn = self._draw_plan(ctx, x)
             try:
                 y = self._forward(x, *args, **kwargs)
             finally:
@@ -119,7 +119,7 @@ class BayesianNetworkModule(Module):
         raise RuntimeError("mc_batched: _forward returned %d rows for batch %d x %d samples"
                            % (y.shape[0], B, samples))
 
-    def _draw_plan(self, ctx):
+    def _draw_plan(self, ctx, x=None):
         """bf16 compute mode: the posteriors of EVERY NormalLinear of the network are drawn for this forward's S samples
         in ONE launch (ops.draw_layers -> bnn_draw_multi) before `_forward` runs; each layer then finds its drawn
         weights (consumed on first use: a layer called twice draws again, like the reference's per-call sample(),
@@ -168,7 +168,16 @@ class BayesianNetworkModule(Module):
             else:
                 pre = ops.draw_layers(specs, ctx.samples, kl=kl)
         if todo3:
-            pre += ops.draw_layers(specs_of(todo3), ctx.samples, kl=kl if (kl is not None and not kl.launched) else None, x3=True)
+            # fp32 parity mode: the network input's three bf16 planes (what the first dense layer would launch bnn_split_bf16x3
+            # for) ride in the same launch; the layer that is called with this very tensor takes them (ctx.x_planes)
+            split = None
+            if x is not None and x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda and x.stride(1) == 1 and x.is_contiguous() and \
+                    x.shape[1] % 8 == 0 and x.data_ptr() % 16 == 0 and not (torch.is_grad_enabled() and x.requires_grad):
+                split = x
+            pre += ops.draw_layers(specs_of(todo3), ctx.samples, kl=kl if (kl is not None and not kl.launched) else None, x3=True, split=split)
+            if split is not None and ops._tls.last_split is not None:
+                ctx.x_planes = (x, ops._tls.last_split)
+                ops._tls.last_split = None
         todo = todo + todo3
         if kl is not None and kl.launched:
             ops._tls.kl_carry = None

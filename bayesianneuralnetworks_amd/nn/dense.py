@@ -205,13 +205,30 @@ class NormalLinear(_NormalSampling, BayesianLinear):
             # fp32 parity mode, inference: the draw-once dense path on three bf16 planes per operand (ops.linear_sampled_x3);
             # a hidden layer that feeds another dense layer hands its result on in that format (out_x3, nn.fuse_activations)
             K = x.shape[-1]
+            ctx = _mc.current()
+            xpl = ctx.x_planes if ctx is not None else None
+            if xpl is not None and torch.is_tensor(x) and shared and x.data_ptr() == xpl[0].data_ptr() and x.shape == xpl[0].shape:
+                x = ops.X3Activation(xpl[1], K)         # the input's planes were split by the draw plan's launch
             x2 = x if isinstance(x, ops.X3Activation) else (x.reshape(-1, K) if shared else x.reshape(S, -1, K))
+            pre3 = predrawn if (predrawn is not None and predrawn.w.dim() == 4) else None
+            # the classifier head behind this layer in the same launch (predictive_mean, nn.fuse_activations(fuse_head=True))?
+            head_pre, head = None, self.__dict__.get("_fuse_head")
+            if head is not None and ctx is not None and ctx.lazy_head and pre3 is not None and head.activation is None:
+                hd = getattr(head, "_predrawn", None)
+                if hd is not None and hd[0] is ctx and head._compute_mode() != "bf16" and \
+                        ops.dense_head_x3_eligible(per, self.weight.mean.shape[0], pre3, hd[1]):
+                    head._predrawn = None
+                    head._adopt_keys(hd[1].key_w, hd[1].key_b)
+                    head_pre = hd[1]
             y = ops.linear_sampled_x3(x2, shared, per, self.weight.mean.detach(), self.weight.scale.detach(),
                                       self.bias.mean.detach() if self.bias is not None else None,
                                       self.bias.scale.detach() if self.bias is not None else None,
                                       keys[0], keys[1], relu=self.activation == 'relu',
                                       planes_out=bool(getattr(self, "out_x3", False)),
-                                      predrawn=predrawn if (predrawn is not None and predrawn.w.dim() == 4) else None)
+                                      predrawn=pre3, head_pre=head_pre)
+            if isinstance(y, ops.HeadPartials):
+                y.head = head
+                return y
             if isinstance(y, ops.X3Activation):
                 return y
             return y.reshape(S * per, y.shape[-1])

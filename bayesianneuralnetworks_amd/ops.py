@@ -175,12 +175,15 @@ def side_stream(device):
     return st
 
 
-def draw_layers(layers, nsamples, kl=None, stream=None, x3=False):
+def draw_layers(layers, nsamples, kl=None, stream=None, x3=False, split=None):
     """ONE launch (bnn_draw_multi) draws the weights and biases of every (mu_w, rho_w, mu_b, rho_b, key_w, key_b) in
     `layers` for `nsamples` MC samples -> list of Predrawn.  kl (a KlDeferred from kl_normal_begin(carry=True)): the
     launch also carries that KL's first pass.  At most 4 layers (8 tensors) per launch; more are split.
     stream: launch on that side stream (forked from the current one here; consumers join through Predrawn.wait()).
-    x3: weights as three bf16 planes of the fp32 draw (BNN_BF16X3; the fp32 parity mode's dense path)."""
+    x3: weights as three bf16 planes of the fp32 draw (BNN_BF16X3; the fp32 parity mode's dense path).
+    split (x3 only): an fp32 (M, K) activation whose three-plane split (what split_x3 returns) rides in the FIRST launch as one more
+    tensor (kind 3) instead of a launch of its own; the planes come back as `_tls.last_split`."""
+    _tls.last_split = None
     out = []
     lib = _lib.load()
     dev = layers[0][0].device
@@ -190,11 +193,24 @@ def draw_layers(layers, nsamples, kl=None, stream=None, x3=False):
     launch_stream = stream if stream is not None else cur
     sp = _lib.stream_ptr(dev)
     sp.value = launch_stream.cuda_stream
-    for i0 in range(0, len(layers), 4):
-        group = layers[i0:i0 + 4]
-        arr = (_lib.DrawTensor * (2 * len(group)))()
+    step = 4 if split is None else 3                # (8 tensors per launch: the split takes one)
+    for i0 in range(0, len(layers), step):
+        group = layers[i0:i0 + step]
+        arr = (_lib.DrawTensor * (2 * len(group) + 1))()
         n = 0
         keep = []
+        if split is not None and i0 == 0 and x3:
+            require_cuda_f32(split, "x")
+            Ms, Ks = split.shape
+            lds_ = _pad64(Ks)
+            planes = torch.empty((3, 1, Ms, lds_), dtype=torch.bfloat16, device=dev)
+            t = arr[n]
+            t.mu, t.rho, t.rows, t.cols = split.data_ptr(), split.data_ptr(), Ms, Ks
+            t.out, t.ld, t.out_sample_stride, t.out_dtype = planes.data_ptr(), lds_, Ms * lds_, _lib.BF16X3
+            t.kind, t.taps = 3, 0
+            n += 1
+            _tls.last_split = planes
+            keep.append(split)
         for spec in group:
             mu_w, rho_w, mu_b, rho_b, key_w, key_b = spec[:6]
             taps = spec[6] if len(spec) > 6 else 0      # KH * KW: a conv weight, written tap-major
@@ -330,6 +346,27 @@ def _dense_head_raw(x2, x_sample_stride, M, pre, K, relu, pre_head, ldx=None):
     return HeadPartials(P)
 
 
+def dense_head_x3_eligible(M, N, pre, pre_head):
+    """The same pair in the fp32 parity mode (three-plane operands): the 160-column tiles only (N % 80 == 0 or N < 128, N > 80)."""
+    return (pre is not None and pre_head is not None and pre.w.dim() == 4 and pre_head.w.dim() == 4 and N > 80 and N % 8 == 0 and
+            (N % 80 == 0 or N < 128) and pre_head.w.shape[2] <= 16 and pre_head.w.shape[3] >= N and pre.w.shape[1] == pre_head.w.shape[1] and M > 0)
+
+
+def _dense_head_raw_x3(xp, shared, M, pre, K, relu, pre_head):
+    """bnn_dense_forward_x3_head: xp (3, S or 1, M, ldx) planes, pre.w (3, S, N, kp), pre_head.w (3, S, Nh, kph) -> HeadPartials."""
+    _, S, N, kp = pre.w.shape
+    _, _, Nh, kph = pre_head.w.shape
+    ldx = xp.shape[3]
+    lib = _lib.load()
+    parts = lib.bnn_dense_head_parts(M, N, S)
+    P = torch.empty((parts, S, M, Nh), dtype=torch.float32, device=xp.device)
+    check(lib.bnn_dense_forward_x3_head(ptr(xp), xp.shape[1] * M * ldx, 0 if shared else M * ldx, ldx,
+                                        ptr(pre.w), S * N * kp, N * kp, kp, ptr(pre.b), N if pre.b is not None else 0,
+                                        ptr(pre_head.w), S * Nh * kph, Nh * kph, kph, ptr(pre_head.b), Nh if pre_head.b is not None else 0, Nh,
+                                        ptr(P), M, N, K, S, _lib.FLAG_RELU if relu else 0, stream_ptr(xp.device)), "bnn_dense_forward_x3_head")
+    return HeadPartials(P)
+
+
 class X3Activation:
     """A hidden activation of the fp32 parity mode as it travels between two dense layers: the fp32 values as three bf16
     planes (3, S, M, ld) (h, m, l: v = h + m + l to 2^-24 |v|), `cols` valid columns.  Not a tensor: only NormalLinear
@@ -403,9 +440,10 @@ def _dense_raw_x3(xp, shared, M, pre, K, relu, planes_out):
     return X3Activation(y, N) if planes_out else y
 
 
-def linear_sampled_x3(x2, shared, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, relu=False, planes_out=False, predrawn=None):
+def linear_sampled_x3(x2, shared, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, relu=False, planes_out=False, predrawn=None, head_pre=None):
     """Inference call of NormalLinear in the fp32 parity mode (no autograd: the caller checked that no gradient is wanted):
-    draw once as three bf16 planes (or `predrawn` by the network's draw plan), contract on the dense kernel."""
+    draw once as three bf16 planes (or `predrawn` by the network's draw plan), contract on the dense kernel.
+    head_pre (the drawn planes of the classifier head behind this layer): the pair as ONE launch -> HeadPartials."""
     S = key_w.nsamples
     N, K = mu_w.shape
     pre = predrawn
@@ -423,6 +461,9 @@ def linear_sampled_x3(x2, shared, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b, rel
         xp = split_x3(x2.reshape(-1, K))            # (3, 1, rows, ld); rows = M (shared) or S * M
         if not shared:
             xp = xp.view(3, S, M, xp.shape[3])
+    if head_pre is not None:
+        head_pre.wait()
+        return _dense_head_raw_x3(xp, shared, M, pre, K, relu, head_pre)
     return _dense_raw_x3(xp, shared, M, pre, K, relu, planes_out)
 
 
@@ -491,6 +532,7 @@ class _ThreadState(threading.local):
     def __init__(self):
         self.kl_carry = None
         self.kl_pending = {}
+        self.last_split = None      # draw_layers(split=...): the three planes of the activation that rode in the last launch
 
 
 _tls = _ThreadState()

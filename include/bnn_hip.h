@@ -240,7 +240,9 @@ typedef struct bnn_draw_tensor {
     int out_dtype;              /* BNN_F32, BNN_BF16, or BNN_BF16X3: three planes, plane p of draw s at
                                  * out + (p * nsamples + s) * out_sample_stride (kind 0) */
     int kind;                   /* 0: draw mu + sigma(rho) eps (rng used); 1: mu itself; 2: sigma(rho) itself (no eps: Flipout's
-                                 * two operands, nsamples = 1) */
+                                 * two operands, nsamples = 1); 3: `mu` as it is, written ONCE whatever nsamples is (rho ignored,
+                                 * pass mu) -- with BNN_BF16X3 (planes out_sample_stride apart) this is bnn_split_bf16x3 of an
+                                 * activation riding in the draw launch: the fp32 parity mode's input planes */
     int taps;                   /* 0 / 1: rows are written as they are.  KH * KW of a conv weight (O, C, KH, KW) viewed as
                                  * (O, C * KH * KW): element (o, c, t) is written to column t * C + c (tap-major, what
                                  * bnn_conv2d_dense_forward reads); the eps stream keeps the original element order */
@@ -279,6 +281,15 @@ int bnn_dense_forward_head(const void *x, int64_t x_sample_stride, int64_t ldx,
                            const void *w_head, int64_t wh_sample_stride, int64_t ldwh,
                            const float *b_head, int64_t bh_sample_stride, int64_t n_head,
                            float *partials, int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream);
+/* bnn_dense_forward_head in the fp32 PARITY mode: x, w and w_head are BNN_BF16X3 operands (plane strides in elements); the fp32
+ * tile of the hidden layer is split into its three bf16 planes in the epilogue and contracted with the head's planes on the six
+ * plane pairs of bnn_dense_forward_x3 (small pairs summed apart from (h, h)).  Partial logits as above, fp32. */
+int bnn_dense_forward_x3_head(const void *x, int64_t x_plane_stride, int64_t x_sample_stride, int64_t ldx,
+                              const void *w, int64_t w_plane_stride, int64_t w_sample_stride, int64_t ldw,
+                              const float *b, int64_t b_sample_stride,
+                              const void *w_head, int64_t wh_plane_stride, int64_t wh_sample_stride, int64_t ldwh,
+                              const float *b_head, int64_t bh_sample_stride, int64_t n_head,
+                              float *partials, int64_t M, int64_t N, int64_t K, int nsamples, int flags, void *stream);
 /* The same layer in the fp32 PARITY mode (1e-5 against the reference) on the same kernel: x and w are BNN_BF16X3 operands
  * (plane p at + p * plane_stride elements; x from bnn_split_bf16x3 or a previous layer's BNN_FLAG_Y_BF16 output, w from
  * bnn_draw_multi with out_dtype BNN_BF16X3) and the contraction runs the six largest partial products of

@@ -101,7 +101,7 @@ def test_multi_gpu_check_arithmetic_on_an_emulated_all_reduce():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,fuse_head", [("bf16", False), ("bf16", True), ("f32", False)])
+@pytest.mark.parametrize("mode,fuse_head", [("bf16", False), ("bf16", True), ("f32", False), ("f32", True)])
 def test_timed_graph_replays_match_oracle(mode, fuse_head):
     sys.path.insert(0, ROOT)
     import bench
@@ -133,11 +133,12 @@ def test_timed_graph_replays_match_oracle(mode, fuse_head):
         # predictive mean (through all three layers) and the KL are checked all the same, and the step is 4 launches, not 5
         step = bench.Step(net, bench.resident_input(x, mode), 0, 1, True, fuse_head=fuse_head)
         assert step.graph is not None and lib.bnn_launch_count() > n0
-        if mode == "bf16":
-            n1 = lib.bnn_launch_count()
-            step._body()
-            torch.cuda.synchronize()
-            assert lib.bnn_launch_count() - n1 == (4 if fuse_head else 5)
+        n1 = lib.bnn_launch_count()
+        step._body()
+        torch.cuda.synchronize()
+        # draw, layer 1, layer 2 (+ head | , head), reduction -- in the fp32 mode too: the split of the input into planes rides
+        # in the draw launch (kind 3)
+        assert lib.bnn_launch_count() - n1 == (4 if fuse_head else 5)
         prev = None
         for k in range(3):
             res = bench.oracle_check(step, post, x_cpu, mode, rows=rows, tap=None if fuse_head else tap)

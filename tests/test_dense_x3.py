@@ -201,8 +201,8 @@ def test_fp32_mode_network_on_dense_path_equals_fused_kernels_and_oracle(env, di
                 outs[x3] = net.forward_stacked(x, S)
             launches = env["lib"].bnn_launch_count() - n0
             if x3:
-                # draw (every layer) + split of the input + one dense launch per layer
-                assert launches == 2 + (len(dims) - 1), launches
+                # draw (every layer; the split of the input into planes rides in it: kind 3) + one dense launch per layer
+                assert launches == 1 + (len(dims) - 1), launches
             keys = [(L.weight.draw_key, L.bias.draw_key) for L in net.layers if hasattr(L, "weight")]
             outs[(x3, "keys")] = keys
     finally:
@@ -225,3 +225,48 @@ def test_fp32_mode_network_on_dense_path_equals_fused_kernels_and_oracle(env, di
                 h = np.maximum(h, 0)
         assert_close_scaled(N(outs[True][s, :48]), h, 1e-5, "dense path vs oracle, sample %d" % s)
         assert_close_scaled(N(outs[False][s, :48]), h, 1e-5, "fused kernels vs oracle, sample %d" % s)
+
+
+X3_HEAD_SHAPES = [  # S, M, N (hidden), K, Nh, shared_x, relu
+    (8, 512, 1200, 1200, 10, False, True),         # the BASELINE pair
+    (8, 512, 1200, 784, 10, True, True),
+    (4, 512, 1200, 1200, 10, False, True),         # 64 x 160 tiles
+    (1, 300, 1200, 264, 16, True, False),          # 32 x 160 tiles, ragged rows
+    (2, 70, 120, 72, 3, False, True),              # N < 128: one ragged panel
+]
+
+
+@pytest.mark.parametrize("S,M,Nn,K,Nh,shared,relu", X3_HEAD_SHAPES)
+def test_fused_head_x3_vs_double(env, S, M, Nn, K, Nh, shared, relu):
+    """bnn_dense_forward_x3_head (fp32 parity mode: hidden layer + classifier head in one launch on three-plane operands) against
+    float64 on the fp32 operands the planes encode -- 1e-5 of the output scale -- and against the two plain three-plane launches."""
+    ops, dev, lib = env["ops"], env["dev"], env["lib"]
+    g = torch.Generator().manual_seed(S * 100 + M + 7)
+    x = torch.randn((M, K) if shared else (S, M, K), generator=g).to(dev)
+    w1 = (torch.randn(S, Nn, K, generator=g) * 0.1).to(dev); b1 = torch.randn(S, Nn, generator=g).to(dev)
+    w2 = (torch.randn(S, Nh, Nn, generator=g) * 0.1).to(dev); b2 = torch.randn(S, Nh, generator=g).to(dev)
+
+    def planes(w):
+        s_, n_, k_ = w.shape
+        kp = (k_ + 63) // 64 * 64
+        wp = torch.zeros(3, s_, n_, kp, dtype=torch.bfloat16, device=dev)
+        wp[:, :, :, :k_] = ops.split_x3(w.reshape(s_ * n_, k_))[:, 0, :, :k_].reshape(3, s_, n_, k_)
+        return wp
+    pre1, pre2 = ops.Predrawn(planes(w1), b1, None, None), ops.Predrawn(planes(w2), b2, None, None)
+    xp = ops.split_x3(x.reshape(-1, K))
+    if not shared:
+        xp = xp.view(3, S, M, xp.shape[3])
+    assert ops.dense_head_x3_eligible(M, Nn, pre1, pre2)
+    n0 = lib.bnn_launch_count()
+    hp = ops._dense_head_raw_x3(xp, shared, M, pre1, K, relu, pre2)
+    assert lib.bnn_launch_count() == n0 + 1
+    got = hp.logits()
+    xd = x.double().cpu() if not shared else x.double().cpu().unsqueeze(0).expand(S, M, K)
+    hh = torch.einsum("smk,snk->smn", xd, w1.double().cpu()) + b1.double().cpu().unsqueeze(1)
+    if relu:
+        hh = hh.clamp_min(0)
+    want = torch.einsum("smk,snk->smn", hh, w2.double().cpu()) + b2.double().cpu().unsqueeze(1)
+    assert_close_scaled(N(got), want.numpy(), 1e-5, "x3 fused head vs float64")
+    y1 = ops._dense_raw_x3(xp, shared, M, pre1, K, relu, True)                  # planes out
+    y2 = ops._dense_raw_x3(y1.planes, False, M, pre2, Nn, False, False)
+    assert_close_scaled(N(got), N(y2), 1e-5, "x3 fused head vs two launches")

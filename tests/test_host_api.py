@@ -148,7 +148,7 @@ def test_draw_once_entry_points_reject_bad_arguments_without_launching():
     assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == _lib.E_UNSUPPORTED and b"cols" in lib.bnn_last_error()
     t[0].cols, t[0].rng.stream = 8, 70000
     assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == -5                       # stream id out of range
-    t[0].rng.stream, t[0].kind = 1, 3
+    t[0].rng.stream, t[0].kind = 1, 4                                                   # kinds 0 .. 3
     assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == -5 and b"kind" in lib.bnn_last_error()
     # dense: weights must be zero-padded to a multiple of 64 columns; K % 8 == 0
     assert lib.bnn_dense_forward(one, 0, 72, one, 16 * 72, 72, None, 0, one, 64, 16, 4, 16, 72, 1, 0, None) == _lib.E_UNSUPPORTED
