@@ -115,6 +115,7 @@ SIGNATURES = {
     "bnn_dense_forward_x3": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _i64, _i64,
                                     _i64, _i64, _i64, _int, _int, _p]),
     "bnn_split_bf16x3": (_int, [_p, _i64, _i64, _i64, _p, _i64, _i64, _p]),
+    "bnn_transpose_bf16": (_int, [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "bnn_conv2d_dense_forward_x3": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape), _int, _int, _p]),
     "bnn_conv2d_dense_forward": (_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape), _int, _int, _p]),
     "bnn_conv2d_flipout_forward": (_int, [_p, _p, _i64, _p, _p, _p, ctypes.POINTER(Conv2dShape), _int, _p]),

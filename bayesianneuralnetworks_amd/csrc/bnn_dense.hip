@@ -1349,6 +1349,41 @@ __global__ __launch_bounds__(256) void k_split_bf16x3(const float *__restrict__ 
     *reinterpret_cast<uint4 *>(o + plane_stride) = m;
     *reinterpret_cast<uint4 *>(o + 2 * plane_stride) = l;
 }
+
+// bf16 (batch x rows x cols, row pitch ld_in) -> its transpose (batch x cols x ld_out), zeros in columns rows .. ld_out - 1: the
+// drawn weights (S x N x ldw) turned into the operand of the INPUT gradient gx[s] = gy[s] . w_s, which the dense kernel
+// contracts over n.  A workgroup moves a 64 x 64 tile through LDS ([c][r], pitch 72 elements: 16-B chunks on the way out).
+__global__ __launch_bounds__(256) void k_transpose_bf16(const uint16_t *__restrict__ in, int64_t in_batch_stride, int64_t ld_in,
+                                                       uint16_t *__restrict__ out, int64_t out_batch_stride, int64_t ld_out,
+                                                       int rows, int cols)
+{
+    constexpr int PITCH = 72;
+    __shared__ __attribute__((aligned(16))) uint16_t T[64 * PITCH];
+    const int r0 = (int)blockIdx.x * 64, c0 = (int)blockIdx.y * 64;
+    const uint16_t *src = in + (int64_t)blockIdx.z * in_batch_stride;
+    uint16_t *dst = out + (int64_t)blockIdx.z * out_batch_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (int)threadIdx.x + 256 * j;
+        const int r = q >> 3, cc = (q & 7) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + r < rows && c0 + cc < cols) v = *reinterpret_cast<const uint4 *>(src + (int64_t)(r0 + r) * ld_in + c0 + cc);
+        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T[(cc + 2 * i) * PITCH + r] = (uint16_t)(e[i] & 0xFFFFu);
+            T[(cc + 2 * i + 1) * PITCH + r] = (uint16_t)(e[i] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (int)threadIdx.x + 256 * j;
+        const int c = q >> 3, rc = (q & 7) * 8;
+        if (c0 + c < cols && r0 + rc < ld_out)
+            *reinterpret_cast<uint4 *>(dst + (int64_t)(c0 + c) * ld_out + r0 + rc) = *reinterpret_cast<const uint4 *>(&T[c * PITCH + rc]);
+    }
+}
 }  // namespace bnn
 
 // the fused head's operands (dense_launch's `head`, NULL = the plain layer)
@@ -1657,6 +1692,24 @@ int bnn_split_bf16x3(const float *x, int64_t rows, int64_t cols, int64_t ldx, vo
     if (items > 0x7FFFFFFF) { set_error("%s: too many elements", who); return BNN_E_RANGE; }
     hipLaunchKernelGGL(k_split_bf16x3, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        x, (int)(cols / 8), ldx, reinterpret_cast<uint16_t *>(out), ld_out, plane_stride, (int)items);
+    return check_launch(who);
+}
+
+int bnn_transpose_bf16(const void *in, int64_t in_batch_stride, int64_t ld_in, void *out, int64_t out_batch_stride, int64_t ld_out,
+                       int64_t rows, int64_t cols, int batch, void *stream)
+{
+    const char *who = "bnn_transpose_bf16";
+    if ((rows == 0 || batch == 0) && cols >= 1) return BNN_OK;
+    if (!in || !out) { set_error("%s: NULL pointer", who); return BNN_E_NULL; }
+    if (rows < 0 || cols < 1 || batch < 0 || ld_in < cols || ld_out < rows) { set_error("%s: bad extent", who); return BNN_E_SHAPE; }
+    if (cols % 8 != 0 || ld_in % 8 != 0 || ld_out % 8 != 0 || in_batch_stride % 8 != 0 || out_batch_stride % 8 != 0 || !al16(in) || !al16(out)) {
+        set_error("%s: needs cols %% 8 == 0 and 16-B aligned rows on both sides", who);
+        return BNN_E_UNSUPPORTED;
+    }
+    if (rows > 0x7FFFFFFF || cols > 0x7FFFFFFF || (cols + 63) / 64 > 65535 || batch > 65535) { set_error("%s: extent too large", who); return BNN_E_RANGE; }
+    hipLaunchKernelGGL(k_transpose_bf16, dim3((unsigned)((ld_out + 63) / 64), (unsigned)((cols + 63) / 64), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const uint16_t *>(in), in_batch_stride, ld_in,
+                       reinterpret_cast<uint16_t *>(out), out_batch_stride, ld_out, (int)rows, (int)cols);
     return check_launch(who);
 }
 

@@ -624,6 +624,7 @@ __global__ __launch_bounds__(2 * W_NT) void k_wgrad_bf16_dma8(const WgradParams 
         const int gen_every = pairs / 4;                           // 4 draw points per sample, TWO Philox blocks each: two
                                                                    // independent chains interleave (a lone chain is latency-bound)
         float4 *my_eps = reinterpret_cast<float4 *>(eps_lds) + (wave * 8) * 64 + lane;
+        const bool pair8 = p.rng.gen == BNN_GEN_PHILOX7_U16 && (p.K & 7) == 0;     // (wave-uniform)
 #pragma unroll
         for (int t = 0; t < NPAIR - 1; ++t) issue_pair(t);
         for (int s = s_lo; s < s_hi; ++s) {
@@ -634,7 +635,26 @@ __global__ __launch_bounds__(2 * W_NT) void k_wgrad_bf16_dma8(const WgradParams 
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NPAIR - 2) * 2 * OPS) : "memory");
                 __syncthreads();                                   // ... and everyone else's; the previous pair's buffers are free
                 issue_pair((pr + NPAIR - 1) % NPAIR);
-                if (!p.plain && pr % gen_every == 0) {
+                if (!p.plain && pair8) {
+                    // 16-bit stream: the quads of lane groups Q and Q ^ 1 (k .. k + 3 and k + 4 .. k + 7 of one n) are the two halves
+                    // of ONE 8-eps Philox block.  Even Q draws the block of (n, k .. k + 7), odd Q the block of (n + 16, k - 4 ..
+                    // k + 3), and each writes its own quad and its neighbour's: one 7-round block per lane and tile pair instead of
+                    // two half-used ones.  Two draw points per sample, two independent chains each.
+                    if (pr % (2 * gen_every) == 0) {
+                        const int Q = lane >> 4, odd = Q & 1;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const int a = (tile >> 1) + c;
+                            const int n = nb + (lane & 15) + 16 * odd, k = kb + a * 16 + 4 * (Q - odd);
+                            float4 za, zb;
+                            eps8_u16(p.rng, keys, edev, (uint32_t)(((int64_t)n * p.K + k) >> 3), sample, za, zb);
+                            float4 *e = my_eps + (tile + 2 * c + odd) * 64;      // tile (a, odd), this lane's slot
+                            e[odd ? -16 : 0] = za;                               // the quad of the even lane group
+                            e[odd ? 0 : 16] = zb;                                // the quad of the odd lane group
+                        }
+                        tile += 4;
+                    }
+                } else if (!p.plain && pr % gen_every == 0) {
                     // tiles (a, 0) and (a, 1): same k, n and n + 16
                     const int a = tile >> 1;
                     const int n = nb + (lane & 15), k = kb + a * 16 + 4 * (lane >> 4);

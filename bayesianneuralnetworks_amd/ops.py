@@ -640,6 +640,30 @@ def _dgrad_plain_raw(gy, w, x_dtype):
     return gx
 
 
+DGRAD_ON_DRAWN = True      # bf16 mode: the input gradient contracts on the weights the forward drew (A/B switch)
+
+
+def _transpose_drawn_raw(w, K):
+    """Drawn weights (S, N, ldw) bf16 -> (S, K, roundup(N, 64)) with zeros beyond column N (bnn_transpose_bf16)."""
+    S, N, ldw = w.shape
+    ldn = _pad64(N)
+    out = torch.empty((S, K, ldn), dtype=torch.bfloat16, device=w.device)
+    check(_lib.load().bnn_transpose_bf16(ptr(w), N * ldw, ldw, ptr(out), K * ldn, ldn, N, K, S, stream_ptr(w.device)),
+          "bnn_transpose_bf16")
+    return out
+
+
+def _dgrad_drawn_raw(gy, w, K):
+    """gx[s] = gy[s] @ w_s on the weights the forward drew (bf16 (S, N, ldw)): transpose once, then the dense kernel
+    (contraction over n) -- the backward on the draw-once path, no second draw.  gy (S, M, N) bf16 -> gx (S, M, K) bf16."""
+    S, M, N = gy.shape
+    wt = _transpose_drawn_raw(w, K)
+    gx = torch.empty((S, M, K), dtype=torch.bfloat16, device=gy.device)
+    check(_lib.load().bnn_dense_forward(ptr(gy), M * N, N, ptr(wt), K * wt.shape[2], wt.shape[2], None, 0, ptr(gx), M * K, K,
+                                         M, K, N, S, _lib.FLAG_Y_BF16, stream_ptr(gy.device)), "bnn_dense_forward")
+    return gx
+
+
 def _sum_samples(t):
     """(S, ...) fp32 -> sum over S (bnn_mc_sum, scale 1)."""
     out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
@@ -676,6 +700,16 @@ class _SampledLinear(torch.autograd.Function):
         K = x.shape[-1]
         if K != mu_w.shape[1]:
             raise BnnHipError("linear: input has %d features, weight expects %d" % (K, mu_w.shape[1]))
+        ctx.drawn_w = None
+        if (track and ctx.needs_input_grad[0] and not shared_x and compute == _lib.COMPUTE_BF16 and DRAW_ONCE_BF16 and DGRAD_ON_DRAWN
+                and dense_eligible(mu_w) and M > 0 and x.dtype == torch.bfloat16 and mu_w.shape[0] > 16 and mu_w.shape[0] % 8 == 0):
+            # training, bf16 mode: the input gradient will contract on THESE drawn weights (kept alive by the graph node)
+            if predrawn is None:
+                predrawn = draw_layers([(mu_w, rho_w, mu_b, rho_b, key_w, key_b)], key_w.nsamples, kl=_tls.kl_carry)[0]
+                if _tls.kl_carry is not None and _tls.kl_carry.launched:
+                    _tls.kl_carry = None
+            if predrawn.w.dim() == 3:
+                ctx.drawn_w = predrawn.w
         y = _linear_sampled_raw(x, 0 if shared_x else M * K, M, mu_w, rho_w, mu_b, rho_b, key_w, key_b,
                                 compute, relu, out_dtype, predrawn, pad_rows=not needs_grad)
         ctx.save_for_backward(x, mu_w, rho_w, rho_b if mu_b is not None else None, y if relu else None, mu_b)
@@ -733,7 +767,9 @@ class _SampledLinear(torch.autograd.Function):
             gx_dtype = torch.float32 if ctx.shared_x else x.dtype
             fused = K % 4 == 0 and N % (8 if _bf(gy) else 4) == 0 and \
                 (compute == _lib.COMPUTE_BF16 or (not _bf(gy) and gx_dtype == torch.float32))
-            if fused:
+            if ctx.drawn_w is not None and _bf(gy) and gx_dtype == torch.bfloat16:
+                gx = _dgrad_drawn_raw(gy, ctx.drawn_w, K)
+            elif fused:
                 gx = torch.empty((S, M, K), dtype=gx_dtype, device=dev)
                 flags = gflag | (_lib.FLAG_Y_BF16 if gx_dtype == torch.bfloat16 else 0)
                 check(lib.bnn_linear_backward_input_sampled(ptr(gy), M * N, N, ptr(mu_w), ptr(rho_w), ptr(gx),

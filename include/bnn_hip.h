@@ -307,6 +307,13 @@ int bnn_dense_forward_x3(const void *x, int64_t x_plane_stride, int64_t x_sample
  * input of the first bnn_dense_forward_x3 of a network.  cols % 8 == 0, 16-B aligned rows. */
 int bnn_split_bf16x3(const float *x, int64_t rows, int64_t cols, int64_t ldx, void *out, int64_t ld_out, int64_t plane_stride,
                      void *stream);
+/* bf16 (batch x rows x cols, row pitch ld_in) -> the transposes (batch x cols x ld_out), columns rows .. ld_out - 1 written as ZEROS:
+ * drawn weights (S x N x ldw, from bnn_draw_multi) as the operand of the input gradient of a training step,
+ *   gx[s] = gy[s] . w_s  =  bnn_dense_forward(x = gy, w = w_s^T (K rows of ld_out >= roundup(N, 64)), M, N' = K, K' = N)
+ * -- the backward of F.linear (pytorch_bayesian/nn/dense.py:60, examples/MNIST/train.py:63-65) on the weights the forward drew,
+ * with no second draw.  cols % 8 == 0, 16-B aligned rows on both sides. */
+int bnn_transpose_bf16(const void *in, int64_t in_batch_stride, int64_t ld_in, void *out, int64_t out_batch_stride, int64_t ld_out,
+                       int64_t rows, int64_t cols, int batch, void *stream);
 
 /* Same contraction with the weights given (F.linear(x, w, b), dense.py:60):
  * w[s] = w + s * w_sample_stride, b[s] = b + s * b_sample_stride (b may be NULL). */

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import allclose, allclose_scaled, load_golden
+from conftest import allclose, allclose_scaled, assert_close_scaled, load_golden
 import seeded
 
 pytestmark = pytest.mark.gpu
@@ -884,11 +884,55 @@ def test_backward_kernels_bf16_mode(env, S, M, Nn, K):
         assert allclose_scaled(N(gx.float()), exact_x, 2e-2)
 
 
-@pytest.mark.parametrize("mode,M", [("f32", 70), ("bf16", 256), ("bf16", 72)])
-def test_bias_gradient_fused_into_weight_gradient(env, mode, M):
+@pytest.mark.parametrize("S,rows,cols,ld_in", [(1, 8, 8, 8), (3, 70, 136, 192), (2, 1200, 1200, 1216), (2, 130, 64, 64), (1, 10, 1200, 1216)])
+def test_transpose_drawn_weights(env, S, rows, cols, ld_in):
+    """bnn_transpose_bf16: (S, rows, cols) bf16 of pitch ld_in -> (S, cols, roundup(rows, 64)), zeros beyond column `rows`;
+    bit-exact (a copy)."""
+    dev = env["dev"]
+    w = torch.randn(S, rows, ld_in, device=dev).bfloat16()
+    out = env["ops"]._transpose_drawn_raw(w[:, :, :ld_in], cols)
+    ldn = (rows + 63) // 64 * 64
+    assert out.shape == (S, cols, ldn)
+    assert torch.equal(out[:, :, :rows], w[:, :, :cols].transpose(1, 2))
+    assert not out[:, :, rows:].any()
+
+
+@pytest.mark.parametrize("wgen", [0, 1])
+@pytest.mark.parametrize("S,M,Nn,K", [(2, 70, 136, 264), (8, 64, 48, 136), (2, 128, 1200, 784)])
+def test_input_gradient_on_the_drawn_weights_equals_the_redraw_path(env, S, M, Nn, K, wgen):
+    """bf16 training: gx = gy . w_s contracts on the weights the forward drew (transpose + dense kernel) -- same bf16 operands as
+    the kernel that re-draws them inside the contraction, so the two agree to fp32 accumulation order, and both with the oracle on
+    bf16-rounded operands."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    orc, dev, ops = env["orc"], env["dev"], env["ops"]
+    mu, rho, x, gy, _, _ = _bwd_case(env, S, M, Nn, K, 4)
+    key = DrawKey(41, 3, 0, S, 5, gen=wgen)
+    eps = [orc.eps_fill(key.seed, key.stream, s, key.epoch_host, 0, (Nn, K), key.gen) for s in range(S)]
+    got = {}
+    n_launch = {}
+    for on in (True, False):
+        ops.DGRAD_ON_DRAWN = on
+        try:
+            xd = x.to(dev).bfloat16().requires_grad_(True)
+            y = ops.linear_sampled(xd, mu.to(dev), rho.to(dev), None, None, key, None, False, compute="bf16", out_dtype=torch.bfloat16)
+            n0 = env["lib"].bnn_launch_count()
+            (got[on],) = torch.autograd.grad(y, (xd,), gy.to(dev).bfloat16())
+            n_launch[on] = env["lib"].bnn_launch_count() - n0
+        finally:
+            ops.DGRAD_ON_DRAWN = True
+    assert n_launch[True] == 2 and n_launch[False] == 1          # transpose + dense launch; the fused re-draw kernel
+    _, _, want = _oracle_linear_bwd(orc, mu, rho, x, gy, eps, False, rounder=orc.bf16_round)
+    assert_close_scaled(N(got[True].float()), want, 1e-2)
+    assert_close_scaled(N(got[False].float()), want, 1e-2)
+    assert_close_scaled(N(got[True].float()), N(got[False].float()), 1e-2)
+
+
+@pytest.mark.parametrize("mode,M,wgen", [("f32", 70, 0), ("bf16", 256, 0), ("bf16", 256, 1), ("bf16", 72, 0), ("bf16", 72, 1)])
+def test_bias_gradient_fused_into_weight_gradient(env, mode, M, wgen):
     """>= 64 output tiles: the k-tile-0 workgroups of the weight-gradient launch also produce the bias
     gradient (column sums by an MFMA against ones, bias draw's backward in the epilogue).  bf16 with
-    M % 256 == 0 takes the LDS-DMA kernel, M = 72 the register-staged one."""
+    M % 256 == 0 takes the LDS-DMA kernel, M = 72 the register-staged one.  wgen = 1: the draws keyed with the 16-bit stream
+    (the bf16 mode's default) -- the LDS-DMA kernel's helper waves then take whole 8-eps blocks, shared by two lane groups."""
     from bayesianneuralnetworks_amd._rng import DrawKey
     orc, dev = env["orc"], env["dev"]
     S, Nn, K = 2, 520, 1024
@@ -899,7 +943,7 @@ def test_bias_gradient_fused_into_weight_gradient(env, mode, M):
     rhob = torch.randn(Nn, generator=gen) * 0.15 - 2.0
     x = torch.randn(S, M, K, generator=gen)
     gy = torch.randn(S, M, Nn, generator=gen)
-    kw, kb = DrawKey(77, 5, 0, S, 2), DrawKey(77, 6, 0, S, 2)
+    kw, kb = DrawKey(77, 5, 0, S, 2, gen=wgen), DrawKey(77, 6, 0, S, 2, gen=wgen)
     adt = torch.float32 if mode == "f32" else torch.bfloat16
     xd = x.to(dev).to(adt)
     mbd, rbd = mub.to(dev).requires_grad_(True), rhob.to(dev).requires_grad_(True)

@@ -166,6 +166,10 @@ def test_draw_once_entry_points_reject_bad_arguments_without_launching():
     assert lib.bnn_split_bf16x3(None, 4, 8, 8, one, 64, 256, None) == -1
     assert lib.bnn_split_bf16x3(one, 4, 12, 12, one, 64, 256, None) == _lib.E_UNSUPPORTED
     assert lib.bnn_split_bf16x3(one, 0, 8, 8, one, 64, 256, None) == 0                   # no rows: nothing to do
+    assert lib.bnn_transpose_bf16(None, 64, 8, one, 64, 8, 4, 8, 1, None) == -1
+    assert lib.bnn_transpose_bf16(one, 64, 12, one, 64, 8, 4, 12, 1, None) == _lib.E_UNSUPPORTED   # cols % 8
+    assert lib.bnn_transpose_bf16(one, 64, 8, one, 64, 8, 16, 8, 1, None) == -2                    # BNN_E_SHAPE: ld_out < rows
+    assert lib.bnn_transpose_bf16(one, 64, 8, one, 64, 8, 0, 8, 1, None) == 0                      # no rows: nothing to do
     t[0].kind, t[0].out_dtype = 1, _lib.BF16X3
     assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == _lib.E_UNSUPPORTED and b"three-plane" in lib.bnn_last_error()
     t[0].kind, t[0].out_dtype = 0, _lib.BF16
