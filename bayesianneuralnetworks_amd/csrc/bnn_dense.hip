@@ -457,20 +457,42 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     __shared__ __attribute__((aligned(16))) char lds[ST * STAGE];
 
     // ---- block decode: sample -> XCD when the samples fill the 8 XCDs
+    // The hardware deals workgroups to the 8 XCDs round-robin (blockIdx % 8).  S % 8 == 0: XCD x runs the samples x, x + 8, ...
+    // Otherwise (a wide layer at S = 1): XCD x takes a CONTIGUOUS eighth of the launch's tiles, so that the ~32 workgroups it runs
+    // at a time are neighbours.  Within a sample the tiles are walked in groups of 4 tile rows, column panel by column panel
+    // (32 consecutive tiles = 4 x 8 tiles: 4 A row blocks + 8 W panels per k-step through that XCD's L2 instead of 1 + 32 -- or,
+    // dealt round-robin, nearly all of both operands through every L2: the 4096^2 layer in the fp32 mode moved 5.65 x its
+    // algorithmic bytes over the fabric).
     const int per_s = p.ntm * p.ntn;
     int s, t;
     {
         const int L = (int)blockIdx.x;
-        if (p.S % 8 == 0 && !(p.flags & kDenseNoXcdMap)) {
+        if (p.flags & kDenseNoXcdMap) {
+            s = L / per_s;
+            t = L % per_s;
+        } else if (p.S % 8 == 0) {
             const int idx = L >> 3;
             s = (L & 7) + 8 * (idx / per_s);
             t = idx % per_s;
         } else {
-            s = L / per_s;
-            t = L % per_s;
+            const int total = per_s * p.S, x = L & 7;
+            const int u = x * (total >> 3) + (x < (total & 7) ? x : (total & 7)) + (L >> 3);    // XCD x: slots base_x .. base_x + count_x - 1
+            s = u / per_s;
+            t = u % per_s;
         }
     }
-    const int mt = t / p.ntn, panel = t % p.ntn;
+    int mt, panel;
+    if (per_s > 32 && !(p.flags & kDenseNoXcdMap)) {
+        constexpr int GM = 4;
+        const int grp = t / (GM * p.ntn), first = grp * GM;
+        const int gm = p.ntm - first < GM ? p.ntm - first : GM;
+        const int v = t - grp * (GM * p.ntn);
+        mt = first + v % gm;
+        panel = v / gm;
+    } else {
+        mt = t / p.ntn;
+        panel = t % p.ntn;
+    }
     const int m0 = mt * BM, n0 = panel * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -654,14 +676,20 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     // round trip in front of the first store (stamps: 2.0 us from the last MFMA to the stores' issue)
     const float *bias = p.bias ? p.bias + (int64_t)s * p.bias_sample_stride : nullptr;
     const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+    // (the 64 x 128 wave tile has no registers for it -- 128 accumulators + 96 fragment registers: the prefetch spilled up to 102
+    // registers there -- and loads the bias in the epilogue, where 2 us are 0.3 % of its launch)
+    constexpr bool BIAS_PRE = TM * TN <= 20;
     float bv[TN][4];
+    auto load_bias = [&]() {
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = nw + b * 16 + fq * 4 + r;
-            bv[b][r] = (bias && n < p.N) ? bias[n] : 0.f;
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int n = nw + b * 16 + fq * 4 + r;
+                bv[b][r] = (bias && n < p.N) ? bias[n] : 0.f;
+            }
+    };
+    if constexpr (BIAS_PRE) load_bias();
     if (DIAG == 0 && (nw >= p.N || mw >= p.M)) {
         // This wave's whole 16 TM x 16 TN tile lies in the padding of the grid (the BASELINE layers: N = 1200 is 7.5 column
         // panels of 160 -- the second wave column of the last panel, 6.25 % of the launch's MFMAs, LDS reads and energy): it keeps
@@ -709,6 +737,7 @@ __global__ __launch_bounds__(512) void k_dense_bf16(const DenseParams p)
     };
 
     // ---- epilogue: bias, activation, store (accumulator lane (i, q), register r = output row i, column 4 q + r of a 16 x 16 block)
+    if constexpr (!BIAS_PRE) load_bias();               // (the fragment registers are dead here: one exposed round trip)
     const int64_t ybase = (int64_t)s * p.y_sample_stride * ESZ;
     // the lane's four values of block (a, b) after bias and activation
     auto vals = [&](int a, int b, float (&v)[4]) {
