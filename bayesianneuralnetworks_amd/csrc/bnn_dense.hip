@@ -1589,7 +1589,6 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         d.perm_taps = t.taps > 1 ? t.taps : 1;
         d.kind = t.kind;
         if (t.kind < 0 || t.kind > 3) { set_error("%s: tensor %d: kind must be 0 (draw), 1 (mean), 2 (stddev) or 3 (as it is, once)", who, i); return BNN_E_RANGE; }
-        if (t.out_dtype == BNN_BF16X3 && t.kind != 0 && t.kind != 3) { set_error("%s: tensor %d: three-plane output is for draws (kind 0) and for kind 3", who, i); return BNN_E_UNSUPPORTED; }
         if (t.taps > 1 && (t.cols % t.taps != 0 || t.out_dtype == BNN_F32)) { set_error("%s: tensor %d: taps must divide cols (bf16 or three-plane output)", who, i); return BNN_E_SHAPE; }
         d.first_item = (int32_t)items;
         d.rng = make_rng(&t.rng);

@@ -1100,6 +1100,18 @@ def conv2d_flipout(x, mean, scale, R, S, stride, padding, dilation):
     return y
 
 
+def conv2d_flipout_x3(x, mean, stddev, R, S, stride, padding, dilation):
+    """FlipOutNormalConv2d.forward (conv.py:207-221) in the fp32 parity mode without the im2col panel: mean and stddev as three
+    bf16 planes each (ONE bnn_draw_multi launch, kind 1), two implicit-GEMM contractions (bnn_conv2d_dense_forward_x3), the sign
+    tensors by torch (no autograd: inference path; the caller checked conv2d_plain_x3_eligible)."""
+    x = x.contiguous()
+    sh, OH, OW = _conv_shape(x.shape, mean.shape, stride, padding, dilation, 1)
+    pm, ps = plain_conv_planes([mean.detach().contiguous(), stddev.detach().contiguous()])
+    out = _conv_planes_raw(x, pm, None, sh, OH, OW)[0]
+    noise = _conv_planes_raw((x * S.expand_as(x)).contiguous(), ps, None, sh, OH, OW)[0]
+    return out + noise * R.expand_as(out)
+
+
 def flipout_conv_weights(mean, scale):
     """[O rows of the mean | O rows of the stddev] as bf16, tap-major, rows zero-padded to a multiple of 64 columns: the
     weight operand of bnn_conv2d_flipout_forward (one bnn_draw_multi launch with kinds 1 / 2 -- no eps)."""
@@ -1209,7 +1221,57 @@ class _PlainConv2d(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+def plain_conv_planes(ws):
+    """Explicit conv weights, each (O, C, KH, KW) fp32, as the three-plane tap-major operands of bnn_conv2d_dense_forward_x3:
+    (3, 1, O, kp) bf16 each -- ONE bnn_draw_multi launch (kind 1: the tensor as it is, no draw)."""
+    dev = ws[0].device
+    arr = (_lib.DrawTensor * len(ws))()
+    outs = []
+    for i, w in enumerate(ws):
+        require_cuda_f32(w, "w")
+        O, C, KH, KW = w.shape
+        K = C * KH * KW
+        kp = _pad64(K)
+        out = torch.empty((3, 1, O, kp), dtype=torch.bfloat16, device=dev)
+        t = arr[i]
+        t.mu, t.rho, t.rows, t.cols = w.data_ptr(), w.data_ptr(), O, K
+        t.out, t.ld, t.out_sample_stride, t.out_dtype = out.data_ptr(), kp, O * kp, _lib.BF16X3
+        t.kind, t.taps = 1, KH * KW
+        outs.append(out)
+    check(_lib.load().bnn_draw_multi(arr, len(ws), 1, None, 0, None, stream_ptr(dev)), "bnn_draw_multi")
+    return outs
+
+
+def _conv_planes_raw(x, planes, b, sh, OH, OW):
+    """conv2d of x (B, C, H, W) fp32 with ONE explicit weight given as planes (plain_conv_planes) in the fp32 parity mode:
+    the implicit GEMM on three bf16 planes per operand, no im2col panel -> (1, B, O, OH, OW)."""
+    kp = planes.shape[3]
+    y = torch.empty((1, sh.B, sh.O, OH, OW), dtype=torch.float32, device=x.device)
+    check(_lib.load().bnn_conv2d_dense_forward_x3(ptr(x), 0, ptr(planes), sh.O * kp, sh.O * kp, kp, ptr(b), sh.O if b is not None else 0,
+                                                   ptr(y), sh.B * sh.O * OH * OW, ctypes.byref(sh), 1, 0, stream_ptr(x.device)),
+          "bnn_conv2d_dense_forward_x3")
+    return y
+
+
+def conv2d_plain_x3_eligible(x, w, stride, padding, dilation, groups, compute):
+    """fp32 parity mode, no gradient wanted, one explicit weight (S = 1) of a shape the three-plane implicit GEMM takes."""
+    if not (CONV_X3_F32 and _compute_code(compute) == _lib.COMPUTE_F32 and x.is_cuda and x.dim() == 4 and w.dim() == 5 and w.shape[0] == 1):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return False
+    if x.dtype != torch.float32 or w.dtype != torch.float32 or x.shape[1] != w.shape[2] * groups:
+        return False
+    sh, OH, OW = _conv_shape(x.shape, w.shape[1:], stride, padding, dilation, groups)
+    return OH >= 1 and OW >= 1 and conv_dense_x3_eligible(sh, OH, OW)
+
+
 def conv2d_plain(x, w, b, shared_x, stride, padding, dilation, groups, compute="f32"):
+    if shared_x and conv2d_plain_x3_eligible(x, w, stride, padding, dilation, groups, compute):
+        # inference in the fp32 parity mode: no panel (FlipOutNormalConv2d's two contractions, MC-dropout-free plain layers)
+        x, w0 = x.contiguous(), w[0].detach().contiguous()
+        if w0.data_ptr() % 16 == 0 and (b is None or b.is_cuda):
+            sh, OH, OW = _conv_shape(x.shape, w0.shape, stride, padding, dilation, groups)
+            return _conv_planes_raw(x, plain_conv_planes([w0])[0], None if b is None else b.detach().contiguous().float(), sh, OH, OW)
     return _PlainConv2d.apply(x.contiguous(), w.contiguous(), None if b is None else b.contiguous(), shared_x,
                               (tuple(stride), tuple(padding), tuple(dilation), int(groups)),
                               _compute_code(compute))

@@ -238,7 +238,7 @@ typedef struct bnn_draw_tensor {
     int64_t ld;                 /* >= cols (% 8 == 0 when rows > 1); columns cols .. ld - 1 are written as ZEROS */
     int64_t out_sample_stride;  /* elements */
     int out_dtype;              /* BNN_F32, BNN_BF16, or BNN_BF16X3: three planes, plane p of draw s at
-                                 * out + (p * nsamples + s) * out_sample_stride (kind 0) */
+                                 * out + (p * nsamples + s) * out_sample_stride (kinds 0, 1, 2) */
     int kind;                   /* 0: draw mu + sigma(rho) eps (rng used); 1: mu itself; 2: sigma(rho) itself (no eps: Flipout's
                                  * two operands, nsamples = 1); 3: `mu` as it is, written ONCE whatever nsamples is (rho ignored,
                                  * pass mu) -- with BNN_BF16X3 (planes out_sample_stride apart) this is bnn_split_bf16x3 of an

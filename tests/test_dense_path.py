@@ -608,6 +608,35 @@ def test_predictive_mean_fuses_the_head_and_matches_forward_stacked(env):
         bnn.set_compute("f32")
 
 
+@pytest.mark.parametrize("B,C,O,HW,k,st,pad", [(37, 64, 64, 6, 3, 2, 1), (9, 128, 128, 4, 3, 1, 1), (1024, 64, 64, 6, 3, 2, 1)])
+def test_flipout_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, HW, k, st, pad):
+    """FlipOutNormalConv2d in the fp32 PARITY mode at inference: mean and stddev as three bf16 planes (one launch), two
+    implicit-GEMM contractions on three-plane operands, no im2col panel -- conv.py:207-221 evaluated by torch in float64 on the
+    layer's own mean / stddev / signs, EVERY image, 1e-5 of the output scale; with gradients wanted the panel path, same values."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import FlipOutNormalConv2d
+    dev, lib = env["dev"], env["lib"]
+    torch.manual_seed(B + C + 3)
+    layer = FlipOutNormalConv2d(C, O, k, stride=st, padding=pad).to(dev)
+    x = torch.randn(B, C, HW, HW, generator=torch.Generator().manual_seed(4)).to(dev)
+    bnn.set_compute("f32")
+    n0 = lib.bnn_launch_count()
+    with torch.no_grad():
+        y = layer(x)
+    n_hip = lib.bnn_launch_count() - n0
+    R, S = layer.sampled
+    F = torch.nn.functional
+    x64, m64, s64 = x.double().cpu(), layer.weight.mean.detach().double().cpu(), layer.weight.stddev.detach().double().cpu()
+    want = (F.conv2d(x64, m64, None, st, pad) + F.conv2d(x64 * S.double().cpu().expand_as(x64), s64, None, st, pad) * R.double().cpu())
+    assert_close_scaled(N(y), want.numpy(), 1e-5, "fp32-mode Flipout conv vs float64")
+    xg = x.clone().requires_grad_(True)
+    yg = layer(xg, sample=False)                          # gradients wanted: the two-convolution panel path on the same signs
+    assert yg.requires_grad
+    assert_close_scaled(N(yg), N(y), 2e-5, "panel path vs implicit GEMM")
+    # (K1's stddev launch may or may not be cached by the layer; the contractions themselves are 1 planes launch + 2 GEMMs)
+    assert n_hip <= 5, n_hip
+
+
 @pytest.mark.parametrize("B,C,O,H,W,k,st,pad,dil,shared", CONV_CASES)
 def test_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, H, W, k, st, pad, dil, shared):
     """NormalConv2d in the fp32 PARITY mode at inference (bnn_conv2d_dense_forward_x3: weights drawn as three bf16 planes,
