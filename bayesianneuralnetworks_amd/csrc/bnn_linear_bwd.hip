@@ -899,7 +899,9 @@ struct HeadBwdParams {
     RngDev rng;
 };
 
-constexpr int H_NMAX = 16, H_ROWS = 128;                         // rows per workgroup (gridDim.z row slices per sample)
+// rows per workgroup (gridDim.z row slices per sample).  256: the BASELINE head is 19 x 8 x 2 = 304 workgroups, all resident at
+// once (66 KiB of LDS each: two per CU) -- with 128 rows the 608 workgroups ran as two rounds (23.7 us; now see DESIGN)
+constexpr int H_NMAX = 16, H_ROWS = 256;
 
 template <bool XBF, bool GXBF>
 __global__ __launch_bounds__(256) void k_head_bwd(const HeadBwdParams p)
@@ -1054,6 +1056,66 @@ __global__ void k_head_colsum_fold(const float *__restrict__ cs, float *__restri
     float t = 0.f;
     for (int zz = 0; zz < Z; ++zz) t += cs[((int64_t)s * Z + zz) * N + n];
     out[i] = t;
+}
+
+// The tail of the narrow layer's backward in ONE launch (it was four: k_wgrad_reduce, k_head_colsum_fold, k_sample_affine_bwd,
+// k_kl_backward -- 26 us of 4-10-us launches for 12 k weights): blocks 0 .. nbw - 1 sum the (sample, row slice) slabs of the
+// weight gradient in a fixed order (k_wgrad_reduce's arithmetic), the LAST block folds the column sums of gy over the row slices
+// and runs the bias draw's backward (k_sample_affine_bwd's arithmetic, same eps) and the bias' KL gradient (k_kl_backward's).
+__global__ __launch_bounds__(256) void k_head_tail(const float *__restrict__ slabs, int64_t slab_stride, int nslab,
+                                                   const float *__restrict__ rho, float *__restrict__ g_mu, float *__restrict__ g_rho,
+                                                   int64_t n, int accumulate, const float *__restrict__ kl_up,
+                                                   const float *__restrict__ mu, float kl_scale, float kl_pm, float kl_ps,
+                                                   const float *__restrict__ cs_parts, int S, int Z, int N,
+                                                   const float *__restrict__ rho_b, RngDev rng_b, float *__restrict__ g_mu_b,
+                                                   float *__restrict__ g_rho_b, const float *__restrict__ mu_b, float kl_scale_b,
+                                                   float kl_pm_b, float kl_ps_b)
+{
+    const int nbw = (int)((n + 255) / 256);
+    if ((int)blockIdx.x < nbw) {
+        const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (e >= n) return;
+        float gm = 0.f, gr = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < nslab; ++g) {
+            gm += slabs[(int64_t)g * slab_stride + e];
+            gr += slabs[(int64_t)g * slab_stride + n + e];
+        }
+        if (kl_up) {
+            float dm, dr;
+            kl_grad_terms(mu[e], rho[e], kl_up[0] * kl_scale, kl_pm, kl_ps, dm, dr);
+            gm += dm;
+            gr += dr;
+        }
+        gr *= dsoftplus(rho[e]);
+        if (accumulate) { gm += g_mu[e]; gr += g_rho[e]; }
+        g_mu[e] = gm;
+        g_rho[e] = gr;
+        return;
+    }
+    const int t = threadIdx.x;
+    if (!cs_parts || t >= N) return;
+    const uint32_t edev = rng_epoch_dev(rng_b);
+    float am = 0.f, ar = 0.f;
+    for (int s = 0; s < S; ++s) {
+        float g = 0.f;
+        for (int z = 0; z < Z; ++z) g += cs_parts[((int64_t)s * Z + z) * N + t];
+        const float4 zz = eps4(rng_b, edev, (uint32_t)(t >> 2), rng_b.sample0 + (uint32_t)s);
+        const float e = (t & 3) == 0 ? zz.x : (t & 3) == 1 ? zz.y : (t & 3) == 2 ? zz.z : zz.w;
+        am += g;
+        ar = fmaf(g, e, ar);
+    }
+    const float ds = dsoftplus(rho_b[t]);
+    float gm = am, gr = ar * ds;
+    if (accumulate) { gm += g_mu_b[t]; gr += g_rho_b[t]; }
+    if (mu_b && kl_up) {
+        float dm, dr;
+        kl_grad_terms(mu_b[t], rho_b[t], kl_up[0] * kl_scale_b, kl_pm_b, kl_ps_b, dm, dr);
+        gm += dm;
+        gr += dr * ds;
+    }
+    g_mu_b[t] = gm;
+    g_rho_b[t] = gr;
 }
 
 // ------------------------------------------------------------------ input gradient, explicit weights
@@ -1417,21 +1479,20 @@ int bnn_linear_backward_narrow_sampled(const void *x, int64_t x_sample_stride, i
     rc = check_launch(who);
     if (rc) return rc;
     const int64_t n = N * K;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws.ws_slabs, p.slab_stride, (int)nslab,
-                       rho_w, g_mu, g_rho, n, accumulate, kl ? kl->upstream : nullptr, kl ? kl->mu_w : nullptr,
-                       kl ? kl->scale_w : 0.f, kl ? kl->prior_mu_w : 0.f, kl ? kl->prior_sigma_w : 1.f);
-    rc = check_launch(who);
-    if (rc || !want_bias) return rc;
-    hipLaunchKernelGGL(k_head_colsum_fold, dim3((unsigned)((nsamples * N + 255) / 256)), dim3(256), 0, st, cs_parts, cs_sum, nsamples, (int)Z, (int)N);
-    rc = check_launch(who);
-    if (rc) return rc;
-    rc = bnn_sample_affine_bwd(cs_sum, N, rho_b, nullptr, 0, rng_b, N, nsamples, g_mu_b, g_rho_b, accumulate, stream);
-    if (!rc && kl && kl->mu_b) {
-        const bnn_kl_tensor_t kt = {kl->mu_b, rho_b, N, kl->prior_mu_b, kl->prior_sigma_b};
-        float *gmp[1] = {g_mu_b}, *grp[1] = {g_rho_b};
-        rc = bnn_kl_backward(&kt, 1, 1.0f / (kl->scale_b * (float)N), kl->upstream, gmp, grp, 1, stream);
+    (void)cs_sum;
+    RngDev rb{};
+    if (want_bias) {
+        rc = check_rng(rng_b, nsamples);
+        if (rc) { set_error("%s: bad rng_b", who); return rc; }
+        rb = make_rng(rng_b);
     }
-    return rc;
+    const bool klb = want_bias && kl && kl->mu_b;
+    hipLaunchKernelGGL(k_head_tail, dim3((unsigned)((n + 255) / 256 + (want_bias ? 1 : 0))), dim3(256), 0, st, ws.ws_slabs, p.slab_stride,
+                       (int)nslab, rho_w, g_mu, g_rho, n, accumulate, kl ? kl->upstream : nullptr, kl ? kl->mu_w : nullptr,
+                       kl ? kl->scale_w : 0.f, kl ? kl->prior_mu_w : 0.f, kl ? kl->prior_sigma_w : 1.f,
+                       want_bias ? cs_parts : nullptr, nsamples, (int)Z, (int)N, rho_b, rb, g_mu_b, g_rho_b,
+                       klb ? kl->mu_b : nullptr, klb ? kl->scale_b : 0.f, klb ? kl->prior_mu_b : 0.f, klb ? kl->prior_sigma_b : 1.f);
+    return check_launch(who);
 }
 
 int bnn_linear_backward_weight(const void *x, int64_t x_sample_stride, int64_t ldx, const void *gy,

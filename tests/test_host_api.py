@@ -170,9 +170,6 @@ def test_draw_once_entry_points_reject_bad_arguments_without_launching():
     assert lib.bnn_transpose_bf16(one, 64, 12, one, 64, 8, 4, 12, 1, None) == _lib.E_UNSUPPORTED   # cols % 8
     assert lib.bnn_transpose_bf16(one, 64, 8, one, 64, 8, 16, 8, 1, None) == -2                    # BNN_E_SHAPE: ld_out < rows
     assert lib.bnn_transpose_bf16(one, 64, 8, one, 64, 8, 0, 8, 1, None) == 0                      # no rows: nothing to do
-    t[0].kind, t[0].out_dtype = 1, _lib.BF16X3
-    assert lib.bnn_draw_multi(t, 1, 1, None, 0, None, None) == _lib.E_UNSUPPORTED and b"three-plane" in lib.bnn_last_error()
-    t[0].kind, t[0].out_dtype = 0, _lib.BF16
     sh = _lib.Conv2dShape(B=2, C=48, H=6, W=6, O=64, KH=3, KW=3, stride_h=1, stride_w=1, pad_h=1, pad_w=1, dil_h=1, dil_w=1, groups=1)
     assert lib.bnn_conv2d_dense_forward(one, 0, one, 0, 448, None, 0, one, 0, ctypes.byref(sh), 1, 0, None) == _lib.E_UNSUPPORTED
     assert b"C = 64" in lib.bnn_last_error()

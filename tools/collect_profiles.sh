@@ -19,6 +19,18 @@ for w in step:run_step.py dense_l2:run_dense_l2.py conv_lenet:"run_conv.py lenet
   bash tools/prof.sh r03_${tag} -- python3 tools/$cmd
 done
 bash tools/prof.sh r03_legs -- python3 tools/run_legs.py both
+bash tools/prof.sh r03_train -- python3 tools/bench_train.py --steps 30 --no-graph
+python3 tools/bench_train.py --steps 50 > gpurun_out/r03_train_step.json 2>/dev/null
+export BNN_DENSE_XCD=0
+bash tools/pmc.sh r03_wide_plain_order_fetch "FETCH_SIZE" -- python3 tools/run_wide.py
+unset BNN_DENSE_XCD
+python3 tools/pmc_summary.py gpurun_out/r03_wide_plain_order_fetch_counters.csv bnn > gpurun_out/r03_pmc_wide_fetch_plain_order.txt
+python3 tools/wide_xcd_ab.py > gpurun_out/r03_wide_tile_order.txt 2>&1
+BNN_DENSE_XCD=0 python3 tools/wide_xcd_ab.py >> gpurun_out/r03_wide_tile_order.txt 2>&1
+python3 tools/coissue_probe.py > gpurun_out/r03_coissue_probe.txt 2>&1
+BNN_DENSE_TILE=3 python3 tools/coissue_probe.py >> gpurun_out/r03_coissue_probe.txt 2>&1
+python3 tools/graph_gap_probe.py > gpurun_out/r03_graph_gap_probe.txt 2>&1
+python3 tools/pipe_parts.py > gpurun_out/r03_pipe_parts.txt 2>&1
 bash tools/prof_trace.sh r03_step 12 -- python3 tools/run_step_graph.py 60
 bash tools/prof_trace.sh r03_pipeline 40 -- python3 tools/run_pipe.py 240 4
 python3 tools/overlap_probe.py > gpurun_out/r03_overlap_probe.txt 2>&1
