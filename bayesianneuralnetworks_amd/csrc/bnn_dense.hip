@@ -63,6 +63,9 @@ struct DrawTensorDev {
     // elements 8 i .. 8 i + 7: a workgroup = 2048 consecutive scalars = one workgroup of the KL's first pass), items pad_first ..
     // the groups of the zero padding (rows x (ld - cols) / 8 of them, written as zeros by workgroups of their own)
     int32_t flat, pad_first;
+    // tapg (a conv weight written tap-major, C % 8 == 0): a workgroup takes whole GROUPS of 8 channels x taps (8 taps consecutive
+    // elements = `taps` work items), transposes them through LDS and stores whole 16-B chunks (tap t, channels c0 .. c0 + 7)
+    int32_t tapg;
     // kl_on: this tensor's KL partial sums are computed by its own draw items (the eight (mu, rho) are in registers): partial
     // kl_first + workgroup index within the tensor; prior as in KlTensorDev
     int32_t kl_on, kl_first;
@@ -192,6 +195,92 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
                 o.z = pack_bf16x2(w[4], w[5]); o.w = pack_bf16x2(w[6], w[7]);
                 *reinterpret_cast<uint4 *>(dst) = o;
             }
+        }
+        return;
+    }
+    if (L.t[ti].tapg) {
+        // ================= a conv weight (O, C, KH, KW), tap-major output =================
+        // Element (o, c, t) sits at flat index (o C + c) taps + t and goes to column t C + c of row o.  A GROUP = the 8 taps
+        // consecutive elements of 8 channels of one row = `taps` items of 8 consecutive elements (one 8-eps block each); its
+        // output is `taps` 16-B chunks.  A workgroup takes ng = 2048 / (8 taps) groups: the items scatter their eight bf16 values
+        // into an LDS image [group][tap][8 channels], then thread i stores chunk i -- instead of eight 2-B stores per item (the
+        // general body: 8.3 us for the 1.18 M draws of the configs[3] layer).  Samples over blockIdx.y.
+        __shared__ __attribute__((aligned(16))) uint16_t timg[3][256 * 8];
+        const int taps = t_taps;
+        const int ng = 2048 / (8 * taps);
+        const int Cn = t_cols / taps, C8 = Cn >> 3;
+        const int NG = t_rows * C8;
+        const int g0 = ((item0 - L.t[ti].first_item) >> 8) * ng;
+        const int i = (int)threadIdx.x;
+        const int gl = i / taps, b = i - gl * taps;                   // local group, item within the group (= tap of phase 2)
+        const bool live = gl < ng && g0 + gl < NG;
+        const int64_t e0 = ((int64_t)(g0 + gl) * taps + b) * 8;       // flat index of the item's first element
+        float m[8], sg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { m[j] = 0.f; sg[j] = 0.f; }
+        if (live) {
+            const float4 m0 = *reinterpret_cast<const float4 *>(t_mu + e0), m1 = *reinterpret_cast<const float4 *>(t_mu + e0 + 4);
+            const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            if (t_kind == 1 || t_kind == 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = mm[j];
+            } else {
+                const float4 r0 = *reinterpret_cast<const float4 *>(t_rho + e0), r1 = *reinterpret_cast<const float4 *>(t_rho + e0 + 4);
+                const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (t_kind == 2) m[j] = sigma_accurate(rr[j]);
+                    else { m[j] = mm[j]; sg[j] = sigma_draw(rr[j]); }
+                }
+            }
+        }
+        // where the item's element j goes in the image: channel (8 b + j) / taps of the group, tap (8 b + j) % taps
+        int pos[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int jj = 8 * b + j, cl = jj / taps, tp = jj - cl * taps;
+            pos[j] = (gl * taps + tp) * 8 + cl;
+        }
+        const int G = g0 + gl;
+        const int orow = live ? G / C8 : 0, cg = live ? G - orow * C8 : 0;
+        const int npl = t_x3 ? 3 : 1;
+        const int64_t sbytes_t = t_stride * 2, pbytes_t = sbytes_t * (t_kind == 3 ? 1 : S);
+        char *const drow = t_out + (int64_t)orow * t_ld * 2;
+        const uint32_t edev = rng_epoch_dev(rng);
+        const PhiloxKeys keys = philox_keys(rng.key0, rng.key1);
+        const bool gen16 = rng.gen == BNN_GEN_PHILOX7_U16;      // (wave-uniform)
+        const int s_end = t_kind == 3 ? 1 : S;
+        for (int s = (int)blockIdx.y; s < s_end; s += (int)gridDim.y) {
+            if (live) {
+                float4 za = make_float4(0.f, 0.f, 0.f, 0.f), zb = za;
+                if (t_kind == 0) {
+                    const uint32_t sample = rng.sample0 + (uint32_t)s, blk = (uint32_t)(e0 >> 2);
+                    if (gen16) eps8_u16(rng, keys, edev, blk >> 1, sample, za, zb);
+                    else { za = eps4(rng, keys, edev, blk, sample); zb = eps4(rng, keys, edev, blk + 1u, sample); }
+                }
+                const float w[8] = {fmaf(sg[0], za.x, m[0]), fmaf(sg[1], za.y, m[1]), fmaf(sg[2], za.z, m[2]), fmaf(sg[3], za.w, m[3]),
+                                    fmaf(sg[4], zb.x, m[4]), fmaf(sg[5], zb.y, m[5]), fmaf(sg[6], zb.z, m[6]), fmaf(sg[7], zb.w, m[7])};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (t_x3) {
+                        uint32_t h, mm_, l;
+                        split_bf16x3(w[j], 0.f, h, mm_, l);
+                        timg[0][pos[j]] = (uint16_t)h; timg[1][pos[j]] = (uint16_t)mm_; timg[2][pos[j]] = (uint16_t)l;
+                    } else timg[0][pos[j]] = f2bf(w[j]);
+                }
+            }
+            __syncthreads();
+            if (live) {
+                char *d = drow + (int64_t)s * sbytes_t + ((int64_t)b * Cn + cg * 8) * 2;
+                for (int pl = 0; pl < npl; ++pl)
+                    *reinterpret_cast<uint4 *>(d + pl * pbytes_t) = *reinterpret_cast<const uint4 *>(&timg[pl][i * 8]);
+                // the zero padding beyond column `cols`: the items of a row's last group write its (ld - cols) / 8 chunks
+                if (cg == C8 - 1)
+                    for (int pc = b; pc < ((t_ld - t_cols) >> 3); pc += taps)
+                        for (int pl = 0; pl < npl; ++pl)
+                            *reinterpret_cast<uint4 *>(drow + (int64_t)s * sbytes_t + pl * pbytes_t + ((int64_t)t_cols + 8 * pc) * 2) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
         }
         return;
     }
@@ -1595,7 +1684,15 @@ int bnn_draw_multi(const bnn_draw_tensor_t *tensors, int ntensors, int nsamples,
         const int64_t nit = t.rows * ((t.ld + 7) / 8);
         d.spread = (nit < kDrawSpreadBelow && nsamples > 1 && nit * nsamples <= 0x7FFFFFFF) ? 1 : 0;
         d.flat = (!d.spread && t.out_dtype != BNN_F32 && t.kind == 0 && t.taps <= 1 && t.cols % 8 == 0 && t.ld % 8 == 0 && al16(t.mu) && al16(t.rho)) ? 1 : 0;
-        if (d.flat) {
+        d.tapg = (t.taps > 1 && t.taps <= 256 && t.out_dtype != BNN_F32 && t.rows >= 1 && (t.cols / t.taps) % 8 == 0 && t.ld % 8 == 0 &&
+                  al16(t.mu) && (t.kind == 1 || t.kind == 3 || al16(t.rho))) ? 1 : 0;
+        static const bool no_tapg = [] { const char *e = getenv("BNN_DRAW_TAPG"); return e && e[0] == '0'; }();
+        if (no_tapg) d.tapg = 0;
+        if (d.tapg) {
+            d.spread = 0;
+            const int64_t ng = 2048 / (8 * t.taps), NG = t.rows * (t.cols / t.taps / 8);
+            items += (NG + ng - 1) / ng * 256;                              // one workgroup per ng groups
+        } else if (d.flat) {
             items += (t.rows * (t.cols / 8) + 255) / 256 * 256;             // the valid groups, flat ...
             d.pad_first = (int32_t)items;
             items += (t.rows * ((t.ld - t.cols) / 8) + 255) / 256 * 256;   // ... and the zero padding's
