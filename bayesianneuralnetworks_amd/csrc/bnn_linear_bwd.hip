@@ -43,6 +43,7 @@ struct WgradParams {
     int64_t slab_stride;        // floats between the partials of two sample groups (nsplit > 1)
     int32_t M, N, K, S, accumulate, ntk, ntn, nsplit, xcd_map;
     int32_t vecX, vecG;         // 16-B loads legal
+    int32_t diag;               // BNN_WGRAD_DIAG (timing only, wrong results): 1 = no fragment reads / MFMAs, 2 = no LDS-DMA
     int32_t plain;              // 1: no draw -- out[s] = dW_s per sample (gridDim.y = S), F.linear's own gradient
     RngDev rng;
     // optional fused bias gradient (nsplit == 1 only): the workgroups of k-tile 0 also take the column sums
@@ -558,6 +559,12 @@ __global__ __launch_bounds__(W_NT) void k_wgrad_bf16_dma(const WgradParams p)
 // them evenly over all pair steps, 8 interleaved chains, measured WORSE: 65 us).  Both roles execute the same barriers: one per pair of
 // images and one (E) per sample, after the helper's last eps write; the helper's first write of the next
 // sample comes after the next pair barrier, which the MFMA waves pass only after their eps reads.
+// Round 3, what bounds the loop (BNN_WGRAD_DIAG, BNN_WGRAD_NOEPS; layer-2 shape, us): full 49.6 (24-bit stream; 48.1 on the 16-bit
+// stream with whole blocks), no eps 30.2, no eps + no fragment reads / MFMAs 29.3, no eps + no DMA 24.9, neither 12.5: the
+// 128 x 64 tile streams 288 MB through LDS per launch (x re-read 19 x, gy 10 x) and THAT is the loop; the MFMAs are 1 us of it.
+// The eps draw adds its full time wherever it runs: moved into the MFMA waves (which "wait" most of a step) -- 4 rows at 2
+// points per sample 52.8, one row at each of 4 points 55.1 (24-bit) / 49.7 (16-bit) -- it was no better than in the helpers.
+// What would help is fewer bytes per FLOP (a 128 x 128 tile: 192 MB), not a better place for the draw.
 __global__ __launch_bounds__(2 * W_NT) void k_wgrad_bf16_dma8(const WgradParams p)
 {
     constexpr int XB = W_BM * W_TK * 2, GB = W_BM * W_TN * 2, NBUF = 8, OPS = 3, BUFB = XB + GB, NPAIR = NBUF / 2;
@@ -607,6 +614,7 @@ __global__ __launch_bounds__(2 * W_NT) void k_wgrad_bf16_dma8(const WgradParams 
         const int64_t x_wrap = (p.x_sample_stride - (int64_t)p.M * p.ldx) * 2, g_wrap = (p.gy_sample_stride - (int64_t)p.M * p.ldgy) * 2;
         int im = 0, left = total;
         auto issue_pair = [&](int pair) {
+            if (p.diag & 2) return;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint32_t base = lds0 + (uint32_t)(2 * pair + h) * BUFB;
@@ -723,6 +731,7 @@ __global__ __launch_bounds__(2 * W_NT) void k_wgrad_bf16_dma8(const WgradParams 
     auto step = [&](auto PAIR) {
         constexpr int pr = decltype(PAIR)::value;
         __syncthreads();                                           // the pair's images have landed (helper waves waited for them)
+        if (p.diag & 1) return;
         compute(std::integral_constant<int, 2 * pr>{});
         compute(std::integral_constant<int, 2 * pr + 1>{});
     };
@@ -1407,6 +1416,8 @@ int bnn_linear_backward_weight_sampled(const void *x, int64_t x_sample_stride, i
     // diagnostic only (timing split of the loop vs the eps epilogue; results are then NOT the gradient)
     static const bool diag_noeps = [] { const char *e = getenv("BNN_WGRAD_NOEPS"); return e && e[0] == '1'; }();
     if (diag_noeps && p.nsplit == 1) p.plain = 1;
+    static const int wdiag = [] { const char *e = getenv("BNN_WGRAD_DIAG"); return e ? atoi(e) : 0; }();
+    p.diag = wdiag;
     p.xcd_map = (p.ntk >= 4 && p.ntn >= 8);
     const dim3 grid(p.xcd_map ? (unsigned)(8 * ((p.ntk + 1) / 2) * ((p.ntn + 3) / 4)) : (unsigned)tiles, (unsigned)p.nsplit);
     const bool dma_ok = p.vecX && p.vecG && M % (8 * W_BM) == 0 && K % 8 == 0 && N % 8 == 0;

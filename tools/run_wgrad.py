@@ -16,7 +16,7 @@ if comp:
     x = x.bfloat16(); gy = gy.bfloat16(); flags = _lib.FLAG_X_BF16 | _lib.FLAG_Y_BF16
 rho = torch.full((N, K), -2.0, device=dev)
 gm = torch.empty(N, K, device=dev); gr = torch.empty(N, K, device=dev)
-kw = ops._rng_struct(DrawKey(1, 1, 0, S, 0), dev)
+kw = ops._rng_struct(DrawKey(1, 1, 0, S, 0, gen=int(os.environ.get("GEN", "0"))), dev)
 st = _lib.stream_ptr(dev)
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 for it in range(iters + 3):
