@@ -444,6 +444,10 @@ __global__ __launch_bounds__(256) void k_draw_multi(const DrawLaunch L)
                 } else
                     rowp[tp * Cn + c] = f2bf(w[j]);
             }
+            // a group that straddles the end of the row (cols % 8 != 0): its padding columns are zeros like the rest of the padding
+            for (int j = nval; j < 8 && c0 + j < t_ld; ++j)
+                for (int pl = 0; pl < (t_x3 ? 3 : 1); ++pl)
+                    *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(rowp + c0 + j) + pl * pbytes) = 0;
         } else {
             // a bias, or the ragged end of a row whose padding starts inside this group: values, then zeros
             for (int j = 0; j < 8; ++j) {

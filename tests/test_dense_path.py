@@ -65,6 +65,37 @@ def test_draw_multi_equals_standalone_sampler_and_oracle(env, shape, S, gen):
         assert np.allclose(N(pre.b[s]), orc.sample_affine(N(mb), N(rb), eb), atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("O,C,k,S,gen,x3", [(64, 64, 3, 8, 1, False), (128, 128, 3, 3, 0, True), (16, 8, 5, 2, 1, False), (5, 16, 7, 2, 0, False),
+                                               (24, 40, 2, 3, 1, True), (3, 8, 1, 2, 0, False), (10, 12, 3, 2, 1, False)])
+def test_conv_weight_draw_tap_major(env, O, C, k, S, gen, x3):
+    """A conv weight (O, C, k, k) drawn tap-major (element (o, c, t) -> column t C + c; C % 8 == 0: groups of 8 channels x taps through
+    LDS, 16-B chunks; C = 12: the general body): the values of K1 on the same key, permuted -- bit for bit --, zero padding, for
+    bf16 and three-plane outputs and both eps streams."""
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    ops, dev = env["ops"], env["dev"]
+    g = torch.Generator().manual_seed(O + C + k)
+    mw = (torch.randn(O, C, k, k, generator=g) * 0.1).to(dev)
+    rw = (torch.randn(O, C, k, k, generator=g) * 0.2 - 2.0).to(dev)
+    kw = DrawKey(31, 7, 1, S, 4, gen=gen)
+    K, taps = C * k * k, k * k
+    pre = ops.draw_layers([(mw.reshape(O, K), rw.reshape(O, K), None, None, kw, None, taps)], S, x3=x3)[0]
+    kp = (K + 63) // 64 * 64
+    w = ops._sample_affine_philox_raw(mw, rw, kw)                                  # (S, O, C, k, k) fp32, the same key
+    want = w.reshape(S, O, C, taps).transpose(2, 3).reshape(S, O, K)              # tap-major
+    if x3:
+        assert pre.w.shape == (3, S, O, kp)
+        h = want.bfloat16()
+        m = (want - h.float()).bfloat16()
+        l = (want - h.float() - m.float()).bfloat16()
+        for got, ref in zip(pre.w, (h, m, l)):
+            assert torch.equal(got[:, :, :K], ref)
+            assert not got[:, :, K:].any()
+    else:
+        assert pre.w.shape == (S, O, kp)
+        assert torch.equal(pre.w[:, :, :K], want.bfloat16())
+        assert not pre.w[:, :, K:].any()
+
+
 def test_draw_multi_many_layers_and_kl_carry(env):
     """Three layers (6 tensors) + the KL first pass in ONE launch; the KL finished by mc_mean equals kl_normal's."""
     from bayesianneuralnetworks_amd._rng import DrawKey
