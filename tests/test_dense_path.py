@@ -137,6 +137,8 @@ DENSE_SHAPES = [  # S, M, N, K, shared_x, relu, y_bf16
     (2, 512, 1200, 784, True, True, True),        # ... of a 4-GPU job: 32 x 160 tiles
     (1, 512, 1200, 1200, False, True, False),     # ... of an 8-GPU job
     (1, 100, 160, 72, True, False, False),        # 64-row tiles with a ragged last tile
+    (3, 1100, 1300, 136, False, True, False),     # S % 8 != 0, 55 tiles of 256 x 128 per sample: XCD-contiguous grouped tile order, ragged
+    (8, 700, 1300, 72, True, False, True),        # S % 8 == 0, 33 tiles per sample: sample -> XCD with grouped tiles inside
     (1, 48, 240, 200, False, True, True),         # 32-row tiles, ragged rows
 ]
 

@@ -824,7 +824,7 @@ def _oracle_linear_bwd(orc, mu, rho, x, gy, eps, shared_x, rounder=None):
 
 
 BWD_SHAPES = [(1, 1, 1, 4), (2, 9, 6, 24), (3, 33, 10, 1200), (2, 70, 130, 260), (8, 64, 48, 136),
-              (2, 5, 7, 11), (1, 40, 3, 9)]
+              (2, 5, 7, 11), (1, 40, 3, 9), (2, 300, 10, 72), (2, 520, 7, 40)]     # (the last two: narrow layer, 2 and 3 row slices)
 
 
 @pytest.mark.parametrize("S,M,Nn,K", BWD_SHAPES)
@@ -974,6 +974,53 @@ def test_bias_gradient_fused_into_weight_gradient(env, mode, M, wgen):
     wm, wr, _ = _oracle_linear_bwd(orc, mu, rho, x, gy, ew, False, rounder=rnd)
     assert allclose_scaled(N(g_mu_w), wm, tol) and allclose_scaled(N(g_rho_w), wr, tol)
     del n0
+
+
+def test_narrow_layer_backward_accumulates_and_folds_bias(env):
+    """bnn_linear_backward_narrow_sampled through the C-ABI: weights, bias (column sums folded over the row slices, the bias draw's
+    backward) and the fused KL gradient leave in ONE tail launch; accumulate = 1 adds to what is there; values against the oracle."""
+    import ctypes
+    from bayesianneuralnetworks_amd import _lib
+    from bayesianneuralnetworks_amd._rng import DrawKey
+    orc, dev, ops, lib = env["orc"], env["dev"], env["ops"], env["lib"]
+    S, M, Nn, K = 3, 300, 10, 72
+    mu, rho, x, gy, _, _ = _bwd_case(env, S, M, Nn, K, 8)
+    g = torch.Generator().manual_seed(5)
+    rhob = torch.randn(Nn, generator=g) * 0.15 - 2.0
+    kw, kb = DrawKey(19, 3, 0, S, 2), DrawKey(19, 4, 0, S, 2)
+    _lib.ensure_workspace(dev)
+    xd, gyd, mud, rhod, rbd = x.to(dev), gy.to(dev), mu.to(dev), rho.to(dev), rhob.to(dev)
+    gm, gr = torch.zeros(Nn, K, device=dev), torch.zeros(Nn, K, device=dev)
+    gmb, grb = torch.zeros(Nn, device=dev), torch.zeros(Nn, device=dev)
+    gx = torch.empty(S, M, K, device=dev)
+    rw, rb = ops._rng_struct(kw, dev), ops._rng_struct(kb, dev)
+    P = _lib.ptr
+
+    def call(acc):
+        n0 = lib.bnn_launch_count()
+        _lib.check(lib.bnn_linear_backward_narrow_sampled(P(xd), M * K, K, P(gyd), M * Nn, Nn, P(mud), P(rhod), P(gx), M * K, K, P(gm), P(gr),
+                                                          P(rbd), P(gmb), P(grb), M, Nn, K, S, ctypes.byref(rw), ctypes.byref(rb), None, 0, acc,
+                                                          _lib.stream_ptr(dev)), "narrow")
+        assert lib.bnn_launch_count() == n0 + 2                   # the pass over the activations + ONE tail launch
+    call(0)
+    first = [t.clone() for t in (gm, gr, gmb, grb)]
+    eps = [orc.eps_fill(kw.seed, kw.stream, s, kw.epoch_host, 0, (Nn, K), kw.gen) for s in range(S)]
+    want_mu, want_rho, want_x = _oracle_linear_bwd(orc, mu, rho, x, gy, eps, False)
+    assert_close_scaled(N(gm), want_mu, 1e-5, "g_mu")
+    assert_close_scaled(N(gr), want_rho, 1e-5, "g_rho")
+    assert_close_scaled(N(gx), want_x, 1e-5, "gx")
+    wb_mu, wb_rho = np.zeros(Nn), np.zeros(Nn)
+    for s in range(S):
+        cs = N(gy[s]).astype(np.float64).sum(0)
+        eb = orc.eps_fill(kb.seed, kb.stream, s, kb.epoch_host, 0, (Nn,), kb.gen)
+        a, b = orc.sample_affine_bwd(np.ones(Nn, np.float32), N(rhob), eb)
+        wb_mu += cs * a
+        wb_rho += cs * b
+    assert_close_scaled(N(gmb), wb_mu, 1e-5, "g_mu_b")
+    assert_close_scaled(N(grb), wb_rho, 1e-5, "g_rho_b")
+    call(1)
+    for t, f in zip((gm, gr, gmb, grb), first):
+        assert torch.allclose(t, 2 * f, rtol=1e-6, atol=1e-7)
 
 
 def test_bias_colsum_and_relu_mask_kernels(env):
