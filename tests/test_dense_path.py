@@ -670,6 +670,32 @@ def test_flipout_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, HW, k, 
     assert n_hip <= 5, n_hip
 
 
+@pytest.mark.parametrize("B,C,O,HW,k,st,pad,bias", [(9, 64, 64, 6, 3, 2, 1, True), (5, 128, 128, 4, 3, 1, 1, False), (3, 64, 128, 5, 1, 1, 0, True)])
+def test_plain_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, HW, k, st, pad, bias):
+    """ops.conv2d_plain with ONE explicit weight at inference in the fp32 parity mode: the weight as three bf16 planes (kind 1,
+    one launch) + the three-plane implicit GEMM -- no im2col panel; float64 conv2d on every image, 1e-5 of the output scale.
+    With a gradient wanted the call stays on the panel kernels (autograd) and agrees."""
+    ops, dev, lib = env["ops"], env["dev"], env["lib"]
+    g = torch.Generator().manual_seed(B + C + O)
+    x = torch.randn(B, C, HW, HW, generator=g)
+    w = torch.randn(1, O, C, k, k, generator=g) * 0.05
+    b = torch.randn(1, O, generator=g) if bias else None
+    xd, wd, bd = x.to(dev), w.to(dev), (b.to(dev) if bias else None)
+    geo = ((st, st), (pad, pad), (1, 1), 1)
+    assert ops.conv2d_plain_x3_eligible(xd, wd, *geo, "f32")
+    n0 = lib.bnn_launch_count()
+    with torch.no_grad():
+        y = ops.conv2d_plain(xd, wd, bd, True, *geo, "f32")
+    assert lib.bnn_launch_count() == n0 + 2                           # planes + contraction
+    want = torch.nn.functional.conv2d(x.double(), w[0].double(), b[0].double() if bias else None, st, pad)
+    assert y.shape == (1,) + tuple(want.shape)
+    assert_close_scaled(N(y[0]), want.numpy(), 1e-5, "plain conv, fp32 mode, implicit GEMM")
+    wg = wd.clone().requires_grad_(True)
+    yg = ops.conv2d_plain(xd, wg, bd, True, *geo, "f32")
+    assert yg.requires_grad
+    assert_close_scaled(N(yg[0]), N(y[0]), 2e-5, "panel path vs implicit GEMM")
+
+
 @pytest.mark.parametrize("B,C,O,H,W,k,st,pad,dil,shared", CONV_CASES)
 def test_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, H, W, k, st, pad, dil, shared):
     """NormalConv2d in the fp32 PARITY mode at inference (bnn_conv2d_dense_forward_x3: weights drawn as three bf16 planes,
