@@ -1374,7 +1374,7 @@ def test_fused_adam_matches_torch_adam(env):
 def test_softmax_cross_entropy_matches_torch(env):
     dev = env["dev"]
     gen = torch.Generator().manual_seed(9)
-    for R, C in ((1, 2), (300, 10), (4096, 10), (257, 33)):
+    for R, C in ((1, 2), (300, 10), (4096, 10), (257, 33), (8192, 10), (9000, 7)):      # (<= 8192 rows: the one-launch kernel)
         x = (torch.randn(R, C, generator=gen) * 4).to(dev).requires_grad_(True)
         y = torch.randint(0, C, (R,), generator=gen).to(dev)
         xr = x.detach().clone().requires_grad_(True)
