@@ -74,7 +74,34 @@ class NormalConv1d(NormalConvNd):
                          _single(padding), _single(dilation), False, groups, bias, prior)
 
     def forward(self, x, sample=True):
-        return self._torch_conv(torch.nn.functional.conv1d, x, sample)
+        if not x.is_cuda or x.dim() not in (2, 3):
+            return self._torch_conv(torch.nn.functional.conv1d, x, sample)
+        # device: a 1-d convolution is the 2-d one on images of height 1 -- the same HIP kernels (implicit GEMM where the shape
+        # allows it), the same draws (the flat element order of (O, C, k) and (O, C, 1, k) is the same)
+        x3 = x.unsqueeze(0) if x.dim() == 2 else x
+        y = _device_conv2d(self, x3.unsqueeze(2), lambda t: t.unsqueeze(2), (1,) + tuple(self.stride), (0,) + tuple(self.padding),
+                           (1,) + tuple(self.dilation), sample).squeeze(2)
+        return y.squeeze(0) if x.dim() == 2 else y
+
+
+def _device_conv2d(layer, x, view, stride, padding, dilation, sample):
+    """NormalConv2d.forward on the device (conv.py:112-119) for a layer whose weight tensors `view` turns into (O, C, KH, KW)."""
+    S, _, shared, per = layer._mc_plan(x, sample)
+    x5 = x if shared else x.reshape(S, per, *x.shape[1:])
+    keys = layer._keys(S)
+    mode = layer._compute_mode()
+    if keys is not None:
+        y = ops.conv2d_sampled(x5, view(layer.weight.mean), view(layer.weight.scale),
+                               layer.bias.mean if layer.bias is not None else None,
+                               layer.bias.scale if layer.bias is not None else None,
+                               keys[0], keys[1], shared, stride, padding, dilation, layer.groups, mode)
+    else:
+        w, b = layer.sampled
+        w = view(w)
+        y = ops.conv2d_plain(x5, w.unsqueeze(0).expand(S, *w.shape),
+                             None if b is None else b.unsqueeze(0).expand(S, -1), shared,
+                             stride, padding, dilation, layer.groups, mode)
+    return y.reshape(S * per, *y.shape[2:])
 
 
 class NormalConv2d(NormalConvNd):
@@ -91,22 +118,7 @@ class NormalConv2d(NormalConvNd):
             return self._torch_conv(torch.nn.functional.conv2d, x, sample)
         if x.dim() == 3:
             return self.forward(x.unsqueeze(0), sample).squeeze(0)
-        S, _, shared, per = self._mc_plan(x, sample)
-        x5 = x if shared else x.reshape(S, per, *x.shape[1:])
-        keys = self._keys(S)
-        mode = self._compute_mode()
-        if keys is not None:
-            y = ops.conv2d_sampled(x5, self.weight.mean, self.weight.scale,
-                                   self.bias.mean if self.bias is not None else None,
-                                   self.bias.scale if self.bias is not None else None,
-                                   keys[0], keys[1], shared, self.stride, self.padding,
-                                   self.dilation, self.groups, mode)
-        else:
-            w, b = self.sampled
-            y = ops.conv2d_plain(x5, w.unsqueeze(0).expand(S, *w.shape),
-                                 None if b is None else b.unsqueeze(0).expand(S, -1), shared,
-                                 self.stride, self.padding, self.dilation, self.groups, mode)
-        return y.reshape(S * per, *y.shape[2:])
+        return _device_conv2d(self, x, lambda t: t, self.stride, self.padding, self.dilation, sample)
 
 
 class NormalConv3d(NormalConvNd):

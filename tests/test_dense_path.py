@@ -670,6 +670,53 @@ def test_flipout_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, HW, k, 
     assert n_hip <= 5, n_hip
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,C,O,L,k,st,pad,dil", [(16, 64, 64, 40, 3, 2, 1, 1), (3, 5, 7, 11, 3, 1, 0, 1), (4, 128, 128, 9, 5, 1, 2, 1), (2, 8, 12, 17, 3, 2, 2, 2)])
+def test_normal_conv1d_on_the_device_kernels(env, B, C, O, L, k, st, pad, dil, mode):
+    """NormalConv1d (conv.py:76-96) on a CUDA input = the conv2d kernels on images of height 1 (implicit GEMM where the shape
+    allows it), same draws: torch's conv1d in float64 on the K1 draw of the recorded keys, every sample, every row; gradients flow
+    to the (O, C, k) Parameters and agree with float64 autograd on the same draws."""
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import NormalConv1d
+    from bayesianneuralnetworks_amd import _mc
+    ops, dev = env["ops"], env["dev"]
+    S = 3
+    torch.manual_seed(B + C + L)
+    layer = NormalConv1d(C, O, k, stride=st, padding=pad, dilation=dil).to(dev)
+    x = torch.randn(B, C, L, generator=torch.Generator().manual_seed(6))
+    xd = x.to(dev)
+    bnn.set_compute(mode)
+    try:
+        bnn.manual_seed(5)
+        with torch.no_grad(), _mc.McContext(S, B, 0):
+            y = layer(xd)
+        OL = y.shape[-1]
+        assert y.shape == (S * B, O, OL)
+        kw, kb = layer.weight.draw_key, layer.bias.draw_key
+        w = ops._sample_affine_philox_raw(layer.weight.mean.detach(), layer.weight.scale.detach(), kw).double().cpu()      # (S, O, C, k)
+        b = ops._sample_affine_philox_raw(layer.bias.mean.detach(), layer.bias.scale.detach(), kb).double().cpu()
+        tol = 1e-5 if mode == "f32" else 2e-2
+        for s in range(S):
+            want = torch.nn.functional.conv1d(x.double(), w[s], b[s], st, pad, dil)
+            assert_close_scaled(N(y[s * B:(s + 1) * B]), want.numpy(), tol, "NormalConv1d %s sample %d" % (mode, s))
+        # backward: same draws (sample=False), gradient w.r.t. the (O, C, k) mean against float64 autograd
+        with _mc.McContext(S, B, 0):
+            yg = layer(xd, sample=False)
+        gy = torch.randn(yg.shape, generator=torch.Generator().manual_seed(8)).to(dev)
+        (g_mu,) = torch.autograd.grad(yg, (layer.weight.mean,), gy)
+        assert g_mu.shape == (O, C, k)
+        x64 = x.double()
+        want_g = torch.zeros(O, C, k, dtype=torch.float64)
+        for s in range(S):
+            ws = w[s].clone().requires_grad_(True)
+            ys_ = torch.nn.functional.conv1d(x64, ws, b[s], st, pad, dil)
+            (gw,) = torch.autograd.grad(ys_, (ws,), gy[s * B:(s + 1) * B].double().cpu())
+            want_g += gw
+        assert_close_scaled(N(g_mu), want_g.numpy(), 1e-4 if mode == "f32" else 3e-2, "NormalConv1d g_mu")
+    finally:
+        bnn.set_compute("f32")
+
+
 @pytest.mark.parametrize("B,C,O,HW,k,st,pad,bias", [(9, 64, 64, 6, 3, 2, 1, True), (5, 128, 128, 4, 3, 1, 1, False), (3, 64, 128, 5, 1, 1, 0, True)])
 def test_plain_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, HW, k, st, pad, bias):
     """ops.conv2d_plain with ONE explicit weight at inference in the fp32 parity mode: the weight as three bf16 planes (kind 1,
