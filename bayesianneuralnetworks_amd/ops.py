@@ -657,6 +657,8 @@ def _dgrad_drawn_raw(gy, w, K):
     """gx[s] = gy[s] @ w_s on the weights the forward drew (bf16 (S, N, ldw)): transpose once, then the dense kernel
     (contraction over n) -- the backward on the draw-once path, no second draw.  gy (S, M, N) bf16 -> gx (S, M, K) bf16."""
     S, M, N = gy.shape
+    if gy.data_ptr() % 16 != 0:                      # (a contiguous view at an odd offset: the LDS-DMA wants 16-B aligned rows)
+        gy = gy.clone()
     wt = _transpose_drawn_raw(w, K)
     gx = torch.empty((S, M, K), dtype=torch.bfloat16, device=gy.device)
     check(_lib.load().bnn_dense_forward(ptr(gy), M * N, N, ptr(wt), K * wt.shape[2], wt.shape[2], None, 0, ptr(gx), M * K, K,
