@@ -137,7 +137,7 @@ class BayesianNetworkModule(Module):
                 continue
             if (m.compute or _settings.get_compute()) == "bf16":
                 todo.append(m)
-            elif ops.DENSE_X3_F32 and (infer or not m.weight.mean.requires_grad) and ctx.base_batch >= 64 and \
+            elif ops.DENSE_X3_F32 and (infer or not m._trainable()) and ctx.base_batch >= 64 and \
                     (m.weight.mean.shape[0] > 16 or m.weight.mean.shape[1] <= 2048):
                 todo3.append(m)         # fp32 parity mode, inference: the same plan with three-plane draws (ops.linear_sampled_x3)
         if not todo and not todo3:

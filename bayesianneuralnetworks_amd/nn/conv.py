@@ -162,7 +162,7 @@ class FlipOutNormalConvNd(NormalConvNd):
             # conv.py:154-161, so they cannot be folded into the weight)
             comp = _settings.get_compute()
             geo = (self.stride, self.padding, self.dilation, self.groups)
-            needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.mean.requires_grad)
+            needs_grad = torch.is_grad_enabled() and (x.requires_grad or self._trainable())
             if comp == "bf16" and not needs_grad and ops.conv2d_flipout_eligible(x, self.weight.mean, *geo):
                 # one launch for both contractions: shared A tile, S in the fragment's sign bits, R in the epilogue
                 return ops.conv2d_flipout(x, self.weight.mean, self.weight.scale, self.R, self.S, *geo[:3])

@@ -94,6 +94,14 @@ class _NormalSampling:
     def _compute_mode(self):
         return self.compute or _settings.get_compute()
 
+    def _trainable(self):
+        """Does any posterior tensor of the layer want a gradient?  (The inference-only paths have no autograd node: a frozen mean
+        with a trainable scale or bias must not take them.)"""
+        ps = [self.weight.mean, self.weight.scale]
+        if self.bias is not None:
+            ps += [self.bias.mean, self.bias.scale]
+        return any(p.requires_grad for p in ps)
+
     def _mc_plan(self, x, sample):
         """-> (S, sample0, shared_x, rows_per_sample) for the current MC context."""
         ctx = _mc.current()
@@ -118,7 +126,7 @@ class _NormalSampling:
         a 2-D fp32 input or an X3Activation, a wide layer."""
         if not ops.DENSE_X3_F32:
             return False
-        if torch.is_grad_enabled() and (self.weight.mean.requires_grad or (torch.is_tensor(x) and x.requires_grad)):
+        if torch.is_grad_enabled() and (self._trainable() or (torch.is_tensor(x) and x.requires_grad)):
             return False
         if torch.is_tensor(x) and (x.dim() != 2 or x.dtype != torch.float32):
             return False

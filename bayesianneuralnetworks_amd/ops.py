@@ -1268,7 +1268,8 @@ def conv2d_plain_x3_eligible(x, w, stride, padding, dilation, groups, compute):
 
 
 def conv2d_plain(x, w, b, shared_x, stride, padding, dilation, groups, compute="f32"):
-    if shared_x and conv2d_plain_x3_eligible(x, w, stride, padding, dilation, groups, compute):
+    bias_grad = torch.is_grad_enabled() and b is not None and b.requires_grad        # (then autograd must see the call)
+    if shared_x and not bias_grad and conv2d_plain_x3_eligible(x, w, stride, padding, dilation, groups, compute):
         # inference in the fp32 parity mode: no panel (FlipOutNormalConv2d's two contractions, MC-dropout-free plain layers)
         x, w0 = x.contiguous(), w[0].detach().contiguous()
         if w0.data_ptr() % 16 == 0 and (b is None or b.is_cuda):

@@ -270,3 +270,36 @@ def test_fused_head_x3_vs_double(env, S, M, Nn, K, Nh, shared, relu):
     y1 = ops._dense_raw_x3(xp, shared, M, pre1, K, relu, True)                  # planes out
     y2 = ops._dense_raw_x3(y1.planes, False, M, pre2, Nn, False, False)
     assert_close_scaled(N(got), N(y2), 1e-5, "x3 fused head vs two launches")
+
+
+def test_inference_paths_are_not_taken_when_only_scale_or_bias_trains(env):
+    """A frozen posterior mean with a trainable scale / bias still needs autograd: the fp32 mode's three-plane dense path and the
+    one-launch Flipout / plain-conv routes have no autograd node and must step aside (they used to look at weight.mean only)."""
+    from bayesianneuralnetworks_amd.nn import NormalLinear, FlipOutNormalConv2d
+    dev, bnn = env["dev"], env["bnn"]
+    bnn.set_compute("f32")
+    torch.manual_seed(4)
+    lin = NormalLinear(64, 32).to(dev)
+    lin.weight.mean.requires_grad_(False)
+    lin.bias.mean.requires_grad_(False)
+    x = torch.randn(128, 64, device=dev)                      # >= 64 rows: eligible for the three-plane path at inference
+    y = lin(x)
+    assert y.requires_grad
+    y.square().sum().backward()
+    assert lin.weight.scale.grad is not None and lin.weight.scale.grad.abs().sum() > 0
+    assert lin.bias.scale.grad is not None and lin.weight.mean.grad is None
+    with torch.no_grad():
+        assert not lin(x).requires_grad                       # ... and with no gradient wanted the inference path runs as before
+    conv = FlipOutNormalConv2d(64, 64, 3, stride=2, padding=1).to(dev)
+    conv.weight.mean.requires_grad_(False)
+    xc = torch.randn(8, 64, 6, 6, device=dev)
+    for mode in ("f32", "bf16"):
+        bnn.set_compute(mode)
+        try:
+            conv.weight.scale.grad = None
+            yc = conv(xc)
+            assert yc.requires_grad, mode
+            yc.square().sum().backward()
+            assert conv.weight.scale.grad is not None and conv.weight.scale.grad.abs().sum() > 0, mode
+        finally:
+            bnn.set_compute("f32")
