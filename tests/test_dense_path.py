@@ -177,6 +177,25 @@ def test_dense_forward_vs_oracle(env, S, M, Nn, K, shared, relu, ybf):
             assert allclose_scaled(got[s], want), np.abs(got[s] - want).max()
 
 
+def _random_dense_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        S = int(rng.choice([1, 2, 3, 4, 5, 8, 9]))
+        M = int(rng.choice([1, 7, 31, 33, 64, 100, 129, 257, 300, 513]))
+        Nn = int(rng.choice([17, 24, 80, 81, 100, 159, 160, 161, 200, 256, 330, 640]))
+        K = 8 * int(rng.randint(1, 90))
+        out.append((S, M, Nn, K, bool(rng.randint(2)), bool(rng.randint(2)), bool(rng.randint(2))))
+    return out
+
+
+@pytest.mark.parametrize("S,M,Nn,K,shared,relu,ybf", _random_dense_shapes(24, 20261005))
+def test_dense_forward_random_shapes_vs_oracle(env, S, M, Nn, K, shared, relu, ybf):
+    """A seeded sweep of ragged shapes over the tile choices (256 x 80, 128 / 64 / 32 x 160, 256 x 128), sample counts that do and
+    do not fill the XCDs, K tails, unaligned output pitches (N % 8 != 0: the scalar store path): the whole matrix against the oracle."""
+    test_dense_forward_vs_oracle(env, S, M, Nn, K, shared, relu, ybf)
+
+
 def test_dense_forward_rejects_unpadded_weights_and_bad_alignment(env):
     lib, _lib, dev = env["lib"], env["_lib"], env["dev"]
     x = torch.zeros(4, 72, dtype=torch.bfloat16, device=dev)
@@ -544,6 +563,22 @@ HEAD_SHAPES = [  # S, M, N (hidden), K, Nh, shared_x, relu
     (3, 130, 72, 200, 10, True, True),             # N <= 80: 256 x 80 tile, one partial per panel
     (2, 260, 264, 328, 7, False, False),           # 256 x 128 tile (N % 80 != 0, N >= 128)
 ]
+
+
+def _random_head_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.choice([1, 2, 3, 5, 8])), int(rng.choice([1, 17, 64, 100, 129, 300])),
+                    8 * int(rng.choice([3, 9, 10, 11, 20, 21, 33, 41])), 8 * int(rng.randint(1, 60)), int(rng.randint(1, 17)),
+                    bool(rng.randint(2)), bool(rng.randint(2))))
+    return out
+
+
+@pytest.mark.parametrize("S,M,Nn,K,Nh,shared,relu", _random_head_shapes(14, 314))
+def test_fused_head_random_shapes(env, S, M, Nn, K, Nh, shared, relu):
+    """A seeded sweep over hidden widths (every tile choice), head widths 1..16, ragged rows and K tails."""
+    test_fused_head_equals_two_dense_launches_and_double(env, S, M, Nn, K, Nh, shared, relu)
 
 
 @pytest.mark.parametrize("S,M,Nn,K,Nh,shared,relu", HEAD_SHAPES)

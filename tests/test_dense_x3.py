@@ -303,3 +303,36 @@ def test_inference_paths_are_not_taken_when_only_scale_or_bias_trains(env):
             assert conv.weight.scale.grad is not None and conv.weight.scale.grad.abs().sum() > 0, mode
         finally:
             bnn.set_compute("f32")
+
+
+def _random_x3_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        Nn = int(rng.choice([8, 16, 24, 80, 88, 160, 168, 200, 264, 400]))
+        K = 8 * int(rng.randint(1, 70))
+        planes = bool(rng.randint(2)) and Nn > 16
+        out.append((int(rng.choice([1, 2, 3, 5, 8])), int(rng.choice([1, 16, 65, 130, 257, 300])), Nn, K, bool(rng.randint(2)),
+                    bool(rng.randint(2)), planes))
+    return out
+
+
+@pytest.mark.parametrize("S,M,Nn,K,shared,relu,planes_out", _random_x3_shapes(18, 77))
+def test_dense_x3_random_shapes(env, S, M, Nn, K, shared, relu, planes_out):
+    """A seeded sweep of ragged shapes over the three-plane dense kernel's tiles and the K-split head kernel (N <= 16)."""
+    test_dense_x3_vs_double(env, S, M, Nn, K, shared, relu, planes_out)
+
+
+def _random_x3_head_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        Nn = int(rng.choice([88, 96, 104, 120, 160, 240, 320, 400, 1200]))          # the 160-column tiles: N % 80 == 0 or N < 128, N > 80
+        out.append((int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 40, 129, 300])), Nn, 8 * int(rng.randint(1, 50)), int(rng.randint(1, 17)),
+                    bool(rng.randint(2)), bool(rng.randint(2))))
+    return out
+
+
+@pytest.mark.parametrize("S,M,Nn,K,Nh,shared,relu", _random_x3_head_shapes(10, 99))
+def test_fused_head_x3_random_shapes(env, S, M, Nn, K, Nh, shared, relu):
+    test_fused_head_x3_vs_double(env, S, M, Nn, K, Nh, shared, relu)
