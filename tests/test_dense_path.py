@@ -327,6 +327,31 @@ CONV_CASES = [  # B, C, O, H, W, k, stride, pad, dil, shared_x
 ]
 
 
+def _random_conv_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        C, O = int(rng.choice([64, 128, 256])), int(rng.choice([64, 128]))
+        H, W = int(rng.randint(2, 9)), int(rng.randint(2, 9))
+        k, st, pad, dil = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2])), int(rng.choice([0, 1, 2])), int(rng.choice([1, 2]))
+        OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // st + 1, (W + 2 * pad - dil * (k - 1) - 1) // st + 1
+        if OH < 1 or OW < 1 or OH * OW > 128 or pad >= k * dil:
+            continue
+        out.append((int(rng.choice([1, 3, 9, 17])), C, O, H, W, k, st, pad, dil, bool(rng.randint(2))))
+    return out
+
+
+@pytest.mark.parametrize("B,C,O,H,W,k,st,pad,dil,shared", _random_conv_cases(16, 4242))
+def test_conv_dense_path_random_shapes(env, B, C, O, H, W, k, st, pad, dil, shared):
+    """A seeded sweep of window / stride / padding / dilation / image sizes over the implicit-GEMM kernel (shapes it does not take
+    are skipped: they run the round-1 kernels, which have their own tests)."""
+    ops = env["ops"]
+    sh, OH, OW = ops._conv_shape((B, C, H, W), (O, C, k, k), (st, st), (pad, pad), (dil, dil), 1)
+    if not ops.conv_dense_eligible(sh, OH, OW):
+        pytest.skip("not a shape of the implicit-GEMM kernel")
+    test_conv_dense_path_vs_oracle(env, B, C, O, H, W, k, st, pad, dil, shared)
+
+
 @pytest.mark.parametrize("B,C,O,H,W,k,st,pad,dil,shared", CONV_CASES)
 def test_conv_dense_path_vs_oracle(env, B, C, O, H, W, k, st, pad, dil, shared):
     """NormalConv2d in bf16 mode (draw once, tap-major + k_conv_bf16) against the oracle's F.conv2d on the same Philox
@@ -776,6 +801,16 @@ def test_plain_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, HW, k, st
     yg = ops.conv2d_plain(xd, wg, bd, True, *geo, "f32")
     assert yg.requires_grad
     assert_close_scaled(N(yg[0]), N(y[0]), 2e-5, "panel path vs implicit GEMM")
+
+
+@pytest.mark.parametrize("B,C,O,H,W,k,st,pad,dil,shared", _random_conv_cases(12, 777))
+def test_conv_f32_mode_random_shapes(env, B, C, O, H, W, k, st, pad, dil, shared):
+    """The same sweep over the three-plane implicit GEMM of the fp32 parity mode."""
+    ops = env["ops"]
+    sh, OH, OW = ops._conv_shape((B, C, H, W), (O, C, k, k), (st, st), (pad, pad), (dil, dil), 1)
+    if not ops.conv_dense_x3_eligible(sh, OH, OW):
+        pytest.skip("not a shape of the three-plane implicit-GEMM kernel")
+    test_conv_f32_mode_without_the_panel_vs_double(env, B, C, O, H, W, k, st, pad, dil, shared)
 
 
 @pytest.mark.parametrize("B,C,O,H,W,k,st,pad,dil,shared", CONV_CASES)
