@@ -898,7 +898,8 @@ def test_transpose_drawn_weights(env, S, rows, cols, ld_in):
 
 
 @pytest.mark.parametrize("wgen", [0, 1])
-@pytest.mark.parametrize("S,M,Nn,K", [(2, 70, 136, 264), (8, 64, 48, 136), (2, 128, 1200, 784)])
+@pytest.mark.parametrize("S,M,Nn,K", [(2, 70, 136, 264), (8, 64, 48, 136), (2, 128, 1200, 784), (3, 256, 24, 8), (2, 384, 200, 1200), (5, 100, 72, 72),
+                                      (1, 1, 328, 40)])
 def test_input_gradient_on_the_drawn_weights_equals_the_redraw_path(env, S, M, Nn, K, wgen):
     """bf16 training: gx = gy . w_s contracts on the weights the forward drew (transpose + dense kernel) -- same bf16 operands as
     the kernel that re-draws them inside the contraction, so the two agree to fp32 accumulation order, and both with the oracle on
