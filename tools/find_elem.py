@@ -1,3 +1,4 @@
+"""Which torch elementwise / copy kernels a bench step launches (torch.profiler over one step): a diagnostic for stray host-side ops."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
