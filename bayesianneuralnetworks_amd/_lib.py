@@ -119,6 +119,7 @@ SIGNATURES = {
     "bnn_conv2d_dense_forward_x3": (_int, [_p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape), _int, _int, _p]),
     "bnn_conv2d_dense_forward": (_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, ctypes.POINTER(Conv2dShape), _int, _int, _p]),
     "bnn_conv2d_flipout_forward": (_int, [_p, _p, _i64, _p, _p, _p, ctypes.POINTER(Conv2dShape), _int, _p]),
+    "bnn_conv2d_flipout_forward_x3": (_int, [_p, _p, _i64, _i64, _p, _p, _p, ctypes.POINTER(Conv2dShape), _int, _p]),
     "bnn_linear_forward": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64,
                                   _int, _int, _int, _p]),
     "bnn_linear_backward_input_sampled": (_int, [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _int,

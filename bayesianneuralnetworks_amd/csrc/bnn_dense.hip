@@ -1148,7 +1148,7 @@ constexpr int kConvLdsBig = 136 * 1024;  // one workgroup per CU with a 6-stage 
 template <int TN, int ST, int LDSB, bool FLIP = false, bool X3 = false>
 __global__ __launch_bounds__(512, LDSB <= 80 * 1024 ? 2 : 1) void k_conv_bf16(const ConvParams p)
 {
-    static_assert(!(FLIP && X3), "the Flipout launch is a bf16-mode path");
+    // (FLIP && X3: the Flipout launch of the fp32 parity mode -- the sign mask flips every plane of the A fragment alike)
     constexpr int NWV = 4, TM = 2, WM = 32, BN = 16 * TN;
     constexpr int B_TOTAL = BN / 8, NBP = B_TOTAL / NWV;        // B pieces per loader per stage (TN = 4: 2, TN = 8: 4)
     constexpr int B_STAGE = BN * 128;
@@ -1842,6 +1842,7 @@ int bnn_transpose_bf16(const void *in, int64_t in_batch_stride, int64_t ld_in, v
     return check_launch(who);
 }
 
+
 }  // extern "C"
 
 static int conv_dense_launch(const float *x, int64_t x_sample_stride, const void *w, int64_t w_sample_stride, int64_t ldw,
@@ -1868,9 +1869,9 @@ static int conv_dense_launch(const float *x, int64_t x_sample_stride, const void
     ConvParams p{};
     const int64_t img_bytes = (int64_t)sh->H * sh->W * sh->C * 2 + (flip ? (sh->C / 8) * 16 : 0);   // + the image's sign masks
     const int P = OH * OW;
-    if (x3 && (flip || w_plane_stride % 8 != 0 || w_plane_stride < (int64_t)sh->O * ldw)) { set_error("%s: bad plane stride", who); return BNN_E_SHAPE; }
+    if (x3 && (w_plane_stride % 8 != 0 || w_plane_stride < (int64_t)bn * ldw)) { set_error("%s: bad plane stride", who); return BNN_E_SHAPE; }
     // ring stages (8 KB / 16 KB each); three-plane operands: the big block for both widths (three image planes), 4 / 3 stages
-    const int st = bn == 64 ? 4 : (flip ? 4 : x3 ? 3 : 6);
+    const int st = bn == 64 ? 4 : (x3 ? 3 : flip ? 4 : 6);
     const int64_t lds_block = (bn == 64 && !x3) ? kConvLds : kConvLdsBig;
     const int64_t ring = (int64_t)st * bn * 128;
     int img = 128 / P;                                  // rows per workgroup <= 128
@@ -1893,7 +1894,10 @@ static int conv_dense_launch(const float *x, int64_t x_sample_stride, const void
     if (grid > 0x7FFFFFFF) { set_error("%s: grid too large", who); return BNN_E_RANGE; }
     const dim3 g((unsigned)grid), blk(512);
     hipStream_t stq = (hipStream_t)stream;
-    if (x3) {
+    if (x3 && flip) {
+        if (bn == 64) hipLaunchKernelGGL((k_conv_bf16<4, 4, kConvLdsBig, true, true>), g, blk, 0, stq, p);
+        else hipLaunchKernelGGL((k_conv_bf16<8, 3, kConvLdsBig, true, true>), g, blk, 0, stq, p);
+    } else if (x3) {
         if (bn == 64) hipLaunchKernelGGL((k_conv_bf16<4, 4, kConvLdsBig, false, true>), g, blk, 0, stq, p);
         else hipLaunchKernelGGL((k_conv_bf16<8, 3, kConvLdsBig, false, true>), g, blk, 0, stq, p);
     } else if (flip) {
@@ -1934,6 +1938,15 @@ int bnn_conv2d_flipout_forward(const float *x, const void *w, int64_t ldw, const
 {
     if (!sign_in || !sign_out) { set_error("bnn_conv2d_flipout_forward: NULL sign tensor"); return BNN_E_NULL; }
     return conv_dense_launch(x, 0, w, 0, ldw, nullptr, 0, sign_in, sign_out, y, 0, sh, 1, flags, stream, "bnn_conv2d_flipout_forward");
+}
+
+int bnn_conv2d_flipout_forward_x3(const float *x, const void *w, int64_t w_plane_stride, int64_t ldw, const float *sign_in,
+                                  const float *sign_out, float *y, const bnn_conv2d_shape_t *sh, int flags, void *stream)
+{
+    if (!sign_in || !sign_out) { set_error("bnn_conv2d_flipout_forward_x3: NULL sign tensor"); return BNN_E_NULL; }
+    if (w_plane_stride <= 0) { set_error("bnn_conv2d_flipout_forward_x3: plane stride of the weights"); return BNN_E_SHAPE; }
+    return conv_dense_launch(x, 0, w, 0, ldw, nullptr, 0, sign_in, sign_out, y, 0, sh, 1, flags, stream, "bnn_conv2d_flipout_forward_x3",
+                             w_plane_stride);
 }
 
 }  // extern "C"

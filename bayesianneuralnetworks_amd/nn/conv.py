@@ -166,6 +166,9 @@ class FlipOutNormalConvNd(NormalConvNd):
             if comp == "bf16" and not needs_grad and ops.conv2d_flipout_eligible(x, self.weight.mean, *geo):
                 # one launch for both contractions: shared A tile, S in the fragment's sign bits, R in the epilogue
                 return ops.conv2d_flipout(x, self.weight.mean, self.weight.scale, self.R, self.S, *geo[:3])
+            if comp == "f32" and not needs_grad and self.groups == 1 and ops.conv2d_flipout_x3_fused_eligible(x, self.weight.mean, *geo[:3]):
+                # fp32 parity mode, inference: ONE contraction launch on three-plane operands (S in the sign bits, R in the epilogue)
+                return ops.conv2d_flipout_x3_fused(x, self.weight.mean, self.weight.stddev, self.R, self.S, *geo[:3])
             if (comp == "f32" and not needs_grad and self.weight.mean.data_ptr() % 16 == 0 and
                     ops.conv2d_plain_x3_eligible(x, self.weight.mean.detach().unsqueeze(0), *geo, comp)):
                 # fp32 parity mode, inference: both contractions as implicit GEMMs on three-plane operands, no im2col panel

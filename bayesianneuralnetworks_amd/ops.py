@@ -1102,10 +1102,54 @@ def conv2d_flipout(x, mean, scale, R, S, stride, padding, dilation):
     return y
 
 
+def conv2d_flipout_x3_fused_eligible(x, mean, stride, padding, dilation):
+    """ONE contraction launch for both of Flipout's convolutions in the fp32 parity mode (bnn_conv2d_flipout_forward_x3): the tile's
+    columns are [O means | O stddevs], so 2 O = 64 or 128, and three planes of an image + the ring fit the LDS block."""
+    O, C, KH, KW = mean.shape
+    if not (CONV_X3_F32 and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and O in (32, 64) and (C == 64 or C % 128 == 0)
+            and mean.data_ptr() % 16 == 0):
+        return False
+    sh, OH, OW = _conv_shape(x.shape, mean.shape, stride, padding, dilation, 1)
+    if OH < 1 or OW < 1 or OH * OW > 128:
+        return False
+    block, st = _CONV_LDS_X3[2 * O]
+    return 3 * (sh.H * sh.W * C * 2 + (C // 8) * 16) + st * 2 * O * 128 <= block and O * OH * OW * 4 <= block
+
+
+def conv2d_flipout_x3_fused(x, mean, stddev, R, S, stride, padding, dilation):
+    """FlipOutNormalConv2d.forward (conv.py:207-221) in the fp32 parity mode in TWO launches: mean and stddev as three bf16 planes,
+    tap-major, stacked [O means | O stddevs] (bnn_draw_multi, kind 1), then ONE implicit GEMM on three-plane operands that shares the
+    A fragment between the two contractions -- S in its sign bits, R in the epilogue (no autograd: inference path)."""
+    x = x.contiguous()
+    O, C, KH, KW = mean.shape
+    K = C * KH * KW
+    kp = _pad64(K)
+    dev = x.device
+    lib = _lib.load()
+    w2 = torch.empty((3, 2 * O, kp), dtype=torch.bfloat16, device=dev)
+    arr = (_lib.DrawTensor * 2)()
+    srcs = (mean.detach().contiguous(), stddev.detach().contiguous())
+    for i, src in enumerate(srcs):
+        require_cuda_f32(src, "weight")
+        t = arr[i]
+        t.mu, t.rho, t.rows, t.cols = src.data_ptr(), src.data_ptr(), O, K
+        t.out, t.ld, t.out_sample_stride, t.out_dtype = w2.data_ptr() + i * O * kp * 2, kp, 2 * O * kp, _lib.BF16X3
+        t.kind, t.taps = 1, KH * KW
+    check(lib.bnn_draw_multi(arr, 2, 1, None, 0, None, stream_ptr(dev)), "bnn_draw_multi")
+    sh, OH, OW = _conv_shape(x.shape, mean.shape, stride, padding, dilation, 1)
+    y = torch.empty((sh.B, O, OH, OW), dtype=torch.float32, device=dev)
+    Sf = S.to(torch.float32).expand(sh.B, C, 1, 1).reshape(sh.B, C).contiguous()
+    Rf = R.to(torch.float32).expand(sh.B, O, 1, 1).reshape(sh.B, O).contiguous()
+    check(lib.bnn_conv2d_flipout_forward_x3(ptr(x), ptr(w2), 2 * O * kp, kp, ptr(Sf), ptr(Rf), ptr(y), ctypes.byref(sh), 0, stream_ptr(dev)),
+          "bnn_conv2d_flipout_forward_x3")
+    return y
+
+
 def conv2d_flipout_x3(x, mean, stddev, R, S, stride, padding, dilation):
     """FlipOutNormalConv2d.forward (conv.py:207-221) in the fp32 parity mode without the im2col panel: mean and stddev as three
     bf16 planes each (ONE bnn_draw_multi launch, kind 1), two implicit-GEMM contractions (bnn_conv2d_dense_forward_x3), the sign
-    tensors by torch (no autograd: inference path; the caller checked conv2d_plain_x3_eligible)."""
+    tensors by torch (no autograd: inference path; the caller checked conv2d_plain_x3_eligible).  Shapes the one-launch form does not
+    take (O = 128)."""
     x = x.contiguous()
     sh, OH, OW = _conv_shape(x.shape, mean.shape, stride, padding, dilation, 1)
     pm, ps = plain_conv_planes([mean.detach().contiguous(), stddev.detach().contiguous()])

@@ -470,6 +470,12 @@ int bnn_conv2d_dense_forward_x3(const float *x, int64_t x_sample_stride,
  * replaces  FlipOutNormalConv2d.forward  pytorch_bayesian/nn/conv.py:207-221 */
 int bnn_conv2d_flipout_forward(const float *x, const void *w, int64_t ldw, const float *sign_in, const float *sign_out,
                                float *y, const bnn_conv2d_shape_t *shape, int flags, void *stream);
+/* The same launch in the fp32 PARITY mode: w = [O mean rows | O stddev rows] as BNN_BF16X3 planes (w_plane_stride elements apart,
+ * >= 2 O ldw; bnn_draw_multi with kind = 1 / 2, taps, out_dtype = BNN_BF16X3 and out_sample_stride = the plane stride), the images
+ * split into three planes in LDS, six plane pairs per 64-k block; S flips the sign bits of every plane of the A fragment alike.
+ * 1e-5 of the output scale against float64.  replaces  FlipOutNormalConv2d.forward  pytorch_bayesian/nn/conv.py:207-221 */
+int bnn_conv2d_flipout_forward_x3(const float *x, const void *w, int64_t w_plane_stride, int64_t ldw, const float *sign_in,
+                                  const float *sign_out, float *y, const bnn_conv2d_shape_t *sh, int flags, void *stream);
 
 /* ---- backward of K2 conv2d through the panel ------------------
  * replaces  autograd through F.conv2d (conv.py:116) for groups == 1, C*KH*KW % 8 == 0.  With
