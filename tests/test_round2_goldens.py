@@ -182,3 +182,54 @@ def test_tolerance_bookkeeping_k784_goldens(env):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "tolerance_bookkeeping.json"), "w") as f:
             json.dump([{"hip_vs_f64": a, "reference_vs_f64": b} for a, b, _ in report], f)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_fashion_mnist_flipout_net_end_to_end(env, mode):
+    """The FashionMNIST example's network (examples/FashionMNIST/model.py:20-33: stock conv prefix, FlipOutNormalConv2d(64, 64, 3, p1,
+    s2), FlipoutNormalLinear(576, 10), Softmax) on the device: the Bayesian tail -- one fused Flipout conv launch in either mode, one
+    contraction for the Flipout linear -- against float64 of conv.py:207-221 / dense.py:70-83 on the layers' own sign tensors,
+    fed the device's own prefix output.  (No reference fixture holds this net's outputs: parity is pinned through the layer-level
+    Flipout goldens, tests/golden/flipout_*.npz, and this float64 restatement.)"""
+    from torch.nn import Conv2d, BatchNorm2d, ELU, Softmax, Flatten, Sequential
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import BayesianNetworkModule, FlipOutNormalConv2d, FlipoutNormalLinear
+    dev = env["dev"]
+
+    class BCNN(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(1, 10, 3)
+            self.layers = Sequential(Conv2d(1, 32, 5, padding=2, stride=2), BatchNorm2d(32), ELU(), Conv2d(32, 32, 3, padding=1, stride=1), ELU(),
+                                     Conv2d(32, 64, 3, padding=0, stride=2), ELU(), FlipOutNormalConv2d(64, 64, 3, padding=1, stride=2), ELU(),
+                                     Flatten(), FlipoutNormalLinear(576, 10), Softmax(dim=-1))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    torch.manual_seed(17)
+    net = BCNN().to(dev).eval()
+    x = torch.randn(48, 1, 28, 28, generator=torch.Generator().manual_seed(2)).to(dev)
+    conv, lin = net.layers[7], net.layers[10]
+    bnn.set_compute(mode)
+    try:
+        n0 = env["lib"].bnn_launch_count()
+        with torch.no_grad():
+            ys = net(x)                                             # 3 stochastic forwards: fresh signs each
+            pre = net.layers[:7](x)
+            y = net._forward(x)                                     # one more, whose signs the layers still hold
+        assert isinstance(ys, list) and len(ys) == 3 and not torch.equal(ys[0], ys[1])
+        assert env["lib"].bnn_launch_count() > n0
+        F = torch.nn.functional
+        p64 = pre.double().cpu()
+        R, S = (t.double().cpu() for t in conv.sampled)
+        m, sd = conv.weight.mean.detach().double().cpu(), conv.weight.stddev.detach().double().cpu()
+        h = F.conv2d(p64, m, None, 2, 1) + F.conv2d(p64 * S.expand_as(p64), sd, None, 2, 1) * R
+        h = F.elu(h).flatten(1)
+        Rl, Sl = (t.double().cpu() for t in lin.sampled)
+        ml, sl = lin.weight.mean.detach().double().cpu(), lin.weight.stddev.detach().double().cpu()
+        z = h @ ml.t() + ((h * Sl) @ sl.t()) * Rl
+        want = torch.softmax(z, -1).numpy()
+        tol = 2e-5 if mode == "f32" else 2e-2
+        assert np.abs(N(y) - want).max() <= tol, (mode, np.abs(N(y) - want).max())
+    finally:
+        bnn.set_compute("f32")
