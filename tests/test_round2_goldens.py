@@ -233,3 +233,59 @@ def test_fashion_mnist_flipout_net_end_to_end(env, mode):
         assert np.abs(N(y) - want).max() <= tol, (mode, np.abs(N(y) - want).max())
     finally:
         bnn.set_compute("f32")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_cifar10_example_net_end_to_end(env, mode):
+    """The CIFAR10 example's network (examples/CIFAR10/model.py:20-38: five stock convolutions, NormalConv2d(128, 128, 3, p1), Linear,
+    MultivariateNormalLinear(128, 10), Softmax) in one MC-batched pass on the device: the prefix runs once, the Bayesian conv launches
+    all samples (draw + implicit GEMM) and is checked against float64 conv2d on the K1 draw of its recorded keys; the tail is torch's
+    (the MVN head's own parity: tests/golden/mvn_linear_128x10.npz)."""
+    from torch.nn import Linear, Conv2d, BatchNorm2d, ELU, Softmax, Flatten, Sequential
+    import bayesianneuralnetworks_amd as bnn
+    from bayesianneuralnetworks_amd.nn import BayesianNetworkModule, NormalConv2d, MultivariateNormalLinear
+    dev, ops = env["dev"], env["ops"]
+    S, B = 4, 16
+
+    class BCNN(BayesianNetworkModule):
+        def __init__(self):
+            super().__init__(3, 10, S)
+            self.layers = Sequential(Conv2d(3, 64, 5, padding=2, stride=2), BatchNorm2d(64), ELU(), Conv2d(64, 128, 5, padding=2, stride=2), ELU(),
+                                     Conv2d(128, 128, 5, padding=2, stride=2), ELU(), Conv2d(128, 128, 3, padding=1), ELU(),
+                                     Conv2d(128, 128, 3, padding=1), ELU(), NormalConv2d(128, 128, 3, padding=1), ELU(), Flatten(),
+                                     Linear(2048, 128), ELU(), MultivariateNormalLinear(128, 10), Softmax(dim=-1))
+
+        def _forward(self, x):
+            return self.layers(x)
+
+    torch.manual_seed(23)
+    net = BCNN().to(dev).eval()
+    net.mc_batched = True
+    x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(dev)
+    conv = net.layers[11]
+    seen = {}
+    hk = conv.register_forward_hook(lambda m, i, o: seen.update(x=i[0].detach(), y=o.detach()))
+    bnn.set_compute(mode)
+    try:
+        bnn.manual_seed(11)
+        n0 = env["lib"].bnn_launch_count()
+        with torch.no_grad():
+            ys = net(x)
+        assert env["lib"].bnn_launch_count() == n0 + 2              # draw + implicit GEMM for all S samples; everything else is torch's
+    finally:
+        bnn.set_compute("f32")
+        hk.remove()
+    assert isinstance(ys, list) and len(ys) == S and all(t.shape == (B, 10) for t in ys)
+    assert all(torch.allclose(t.sum(-1), torch.ones(B, device=dev), atol=1e-5) for t in ys) and not torch.equal(ys[0], ys[1])
+    xin, yout = seen["x"], seen["y"]
+    assert xin.shape == (B, 128, 4, 4) and yout.shape == (S * B, 128, 4, 4)      # the prefix ran ONCE, the Bayesian layer on all samples
+    kw, kb = conv.weight.draw_key, conv.bias.draw_key
+    w = ops._sample_affine_philox_raw(conv.weight.mean.detach(), conv.weight.scale.detach(), kw).double().cpu()
+    b = ops._sample_affine_philox_raw(conv.bias.mean.detach(), conv.bias.scale.detach(), kb).double().cpu()
+    x64 = xin.double().cpu()
+    tol = 1e-5 if mode == "f32" else 2e-2
+    for s in range(S):
+        want = torch.nn.functional.conv2d(x64, w[s], b[s], 1, 1).numpy()
+        got = N(yout[s * B:(s + 1) * B])
+        scale = max(1.0, float(np.sqrt((want ** 2).mean())))
+        assert np.abs(got - want).max() <= tol * scale + tol * np.abs(want).max(), (mode, s, np.abs(got - want).max())
