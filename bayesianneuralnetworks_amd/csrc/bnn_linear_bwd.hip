@@ -912,7 +912,8 @@ struct HeadBwdParams {
 // once (66 KiB of LDS each: two per CU) -- with 128 rows the 608 workgroups ran as two rounds (23.7 us; now see DESIGN)
 constexpr int H_NMAX = 16, H_ROWS = 256;
 
-template <bool XBF, bool GXBF>
+// NP: the output columns the register loops cover (N <= 12 -> 12: a 10-way head skips a quarter of the FMAs of the 16-wide code)
+template <bool XBF, bool GXBF, int NP>
 __global__ __launch_bounds__(256) void k_head_bwd(const HeadBwdParams p)
 {
     // gy rows of this workgroup's slice ([m][n], pitch N) during the row loop; the 16 x 16 partial tiles after it
@@ -951,13 +952,13 @@ __global__ __launch_bounds__(256) void k_head_bwd(const HeadBwdParams p)
         wl[n][tid & 15] = ww;
         zl[n][tid & 15] = zz;
     }
-    float cs[H_NMAX];
+    float cs[NP];
 #pragma unroll
-    for (int n = 0; n < H_NMAX; ++n) cs[n] = 0.f;
+    for (int n = 0; n < NP; ++n) cs[n] = 0.f;
     __syncthreads();
-    float4 w[H_NMAX], dW[H_NMAX];                                  // (eps stays in LDS until the epilogue: 2 x 64 VGPRs, not 3 x)
+    float4 w[NP], dW[NP];                                  // (eps stays in LDS until the epilogue: 2 x 64 VGPRs, not 3 x)
 #pragma unroll
-    for (int n = 0; n < H_NMAX; ++n) {
+    for (int n = 0; n < NP; ++n) {
         dW[n] = make_float4(0.f, 0.f, 0.f, 0.f);
         w[n] = wl[n][kg];
     }
@@ -984,19 +985,19 @@ __global__ __launch_bounds__(256) void k_head_bwd(const HeadBwdParams p)
         for (int u = 0; u < 4; ++u) {
             const int r = r0 + 16 * u;
             if (r < rows) {
-            float g[H_NMAX];
+            float g[NP];
 #pragma unroll
-            for (int q4 = 0; q4 < H_NMAX / 4; ++q4) {
+            for (int q4 = 0; q4 < NP / 4; ++q4) {
                 const float4 t = *reinterpret_cast<const float4 *>(gys + r * H_NMAX + 4 * q4);
                 g[4 * q4] = t.x; g[4 * q4 + 1] = t.y; g[4 * q4 + 2] = t.z; g[4 * q4 + 3] = t.w;
             }
             if (kg == 0 && blockIdx.x == 0) {
 #pragma unroll
-                for (int n = 0; n < H_NMAX; ++n) cs[n] += g[n];
+                for (int n = 0; n < NP; ++n) cs[n] += g[n];
             }
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int n = 0; n < H_NMAX; ++n) {                     // columns >= N carry g = 0, w = 0: straight-line code
+            for (int n = 0; n < NP; ++n) {                         // columns >= N carry g = 0, w = 0: straight-line code
                 dW[n].x = fmaf(g[n], xv[u].x, dW[n].x); dW[n].y = fmaf(g[n], xv[u].y, dW[n].y);
                 dW[n].z = fmaf(g[n], xv[u].z, dW[n].z); dW[n].w = fmaf(g[n], xv[u].w, dW[n].w);
                 o.x = fmaf(g[n], w[n].x, o.x); o.y = fmaf(g[n], w[n].y, o.y);
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const HeadBwdParams p)
     __syncthreads();                                               // gys is dead: its storage becomes the partial tiles
     // fixed-order reduction of the 16 row slices, then (dW, dW * eps) of this (sample, row slice) to its slab
 #pragma unroll
-    for (int n = 0; n < H_NMAX; ++n) {
+    for (int n = 0; n < NP; ++n) {
         part[mp][kg][n * 4 + 0] = dW[n].x; part[mp][kg][n * 4 + 1] = dW[n].y;
         part[mp][kg][n * 4 + 2] = dW[n].z; part[mp][kg][n * 4 + 3] = dW[n].w;
     }
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(const HeadBwdParams p)
         __syncthreads();
         if (kg == 0)
 #pragma unroll
-            for (int n = 0; n < H_NMAX; ++n) part[mp][0][n] = cs[n];
+            for (int n = 0; n < NP; ++n) part[mp][0][n] = cs[n];
         __syncthreads();
         if (tid < N) {
             float t = 0.f;
@@ -1483,10 +1484,15 @@ int bnn_linear_backward_narrow_sampled(const void *x, int64_t x_sample_stride, i
     p.colsums = want_bias ? cs_parts : nullptr;
     p.M = (int32_t)M; p.N = (int32_t)N; p.K = (int32_t)K; p.S = nsamples; p.rng = make_rng(rng_w);
     const dim3 grid((unsigned)((K + 63) / 64), (unsigned)nsamples, (unsigned)Z);
-    if (xh && gxh) hipLaunchKernelGGL((k_head_bwd<true, true>), grid, dim3(256), 0, st, p);
-    else if (xh) hipLaunchKernelGGL((k_head_bwd<true, false>), grid, dim3(256), 0, st, p);
-    else if (gxh) hipLaunchKernelGGL((k_head_bwd<false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_head_bwd<false, false>), grid, dim3(256), 0, st, p);
+#define BNN_HEAD_BWD(NP_) \
+    do { \
+        if (xh && gxh) hipLaunchKernelGGL((k_head_bwd<true, true, NP_>), grid, dim3(256), 0, st, p); \
+        else if (xh) hipLaunchKernelGGL((k_head_bwd<true, false, NP_>), grid, dim3(256), 0, st, p); \
+        else if (gxh) hipLaunchKernelGGL((k_head_bwd<false, true, NP_>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((k_head_bwd<false, false, NP_>), grid, dim3(256), 0, st, p); \
+    } while (0)
+    if (N <= 12) BNN_HEAD_BWD(12); else BNN_HEAD_BWD(16);
+#undef BNN_HEAD_BWD
     rc = check_launch(who);
     if (rc) return rc;
     const int64_t n = N * K;
