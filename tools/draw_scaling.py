@@ -9,6 +9,6 @@ import bench
 lib = _lib.load(); dev = torch.device("cuda:0")
 post = [[t.to(dev) for t in p] for p in bench.posteriors(0)]
 for S in (1, 2, 4, 8, 16, 32):
-    layers = [(mw, rw, mb, rb, DrawKey(1, 2 * i + 1, 0, S, 0), DrawKey(1, 2 * i + 2, 0, S, 0)) for i, (mw, rw, mb, rb) in enumerate(post)]
+    layers = [(mw, rw, mb, rb, DrawKey(1, 2 * i + 1, 0, S, 0, gen=int(os.environ.get("GEN", "1"))), DrawKey(1, 2 * i + 2, 0, S, 0, gen=int(os.environ.get("GEN", "1")))) for i, (mw, rw, mb, rb) in enumerate(post)]
     us = bench._graph_time(lambda: ops.draw_layers(layers, S), dev)
     print("S = %2d: %.2f us" % (S, us))
